@@ -1,0 +1,200 @@
+/*
+ * pt_amd.h -- C ABI of the MI355X-native path-tracing hot path (libptamd.so).
+ *
+ * This is the drop-in boundary for the per-GPU engine of 3DevApps/multi-gpu-path-tracer:
+ * each entry point replaces one piece of the reference's C++ `DevicePathTracer` /
+ * `Framebuffer` / `SceneLoader` / `TaskGenerator` surface (citations are file:line under
+ * the reference's src/).  Plain pointers and sizes only: no HIP, torch or C++ types.
+ *
+ * Threading (mirrors DevicePathTracer.h:194-226 as used by StreamThread.h:64-104):
+ * calls on one pt_device are externally serialised, EXCEPT pt_render_task_async /
+ * pt_stream_sync, which may run concurrently from different host threads on different
+ * streams of the same device.
+ *
+ * Errors: every call returns a pt_status (0 = PT_OK); pt_last_error_string() gives the
+ * thread-local message.  Nothing throws across this boundary.  (The reference prints
+ * "CUDA ERROR = <code> at <file>:<line>" and exit(99)s, cuda_utils.h:6-16; the C++ wrapper
+ * in csrc/host/DevicePathTracer.h reproduces that on top of these codes.)
+ */
+#ifndef PT_AMD_H
+#define PT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_API __attribute__((visibility("default")))
+
+typedef int pt_status;
+enum {
+    PT_OK = 0,
+    PT_ERR_INVALID = 1,      /* bad argument / out-of-range index                              */
+    PT_ERR_HIP = 2,          /* a HIP runtime call failed                                      */
+    PT_ERR_NO_LIGHTS = 3,    /* no emissive face: reference dereferences list[0] of an empty
+                                light list (hitable_list.h:23-26) -> undefined behaviour        */
+    PT_ERR_STACK = 4,        /* BVH needs > 64 traversal-stack entries (bvh.h:179 overflow, UB) */
+    PT_ERR_IO = 5,           /* file missing / malformed                                       */
+    PT_ERR_UNSUPPORTED = 6,  /* valid input this build does not handle                         */
+    PT_ERR_NO_SCENE = 7,     /* render before pt_upload_scene / pt_bind_framebuffer            */
+    PT_ERR_NO_DEVICE = 8     /* no usable gfx950 device: the HIP path is mandatory, there is no
+                                CPU fallback                                                   */
+};
+
+/* ------------------------------------------------------------------ host data model -- */
+/* HostScene.h:28-31 Vertex */
+typedef struct { float position[3]; float texCoords[2]; } pt_vertex;
+/* HostScene.h:41-47 Triangle */
+typedef struct { pt_vertex v0, v1, v2; int textureIdx; int materialIdx; } pt_triangle;
+/* HostScene.h:33-39 HostMaterial; a texture index of -1 is an empty std::optional<int>. */
+typedef struct {
+    float baseColor[3];       int baseColorTextureIdx;
+    float emissiveFactor[3];  int emissiveTextureIdx;
+} pt_material;
+/* HostScene.h:49-53 HostTexture: width*height float3 texels with channel values 0..255. */
+typedef struct { int width, height; const float *data; } pt_texture;
+/* CameraConfig.h:5-17 (pitch / yaw are UI state, not read on this path). */
+typedef struct { float lookFrom[3]; float front[3]; float vfov, hfov; } pt_camera;
+/* DevicePathTracer.h:19-25 RenderTask (the `time` field stays on the C++ wrapper). */
+typedef struct { int width, height, offset_x, offset_y; } pt_task;
+
+/* Exact per-launch work counters: the kernel's own counts. */
+typedef struct {
+    uint64_t paths;        /* camera rays started                                   */
+    uint64_t segments;     /* BVH::hit calls from camera::ray_color (camera.h:55)   */
+    uint64_t box_tests;    /* aabb::hit evaluations (aabb.h:38)                     */
+    uint64_t tri_tests;    /* triangle::hit evaluations inside BVH::hit             */
+    uint64_t light_tests;  /* triangle::hit evaluations inside triangle::pdf_value  */
+} pt_counters;
+
+typedef struct {
+    uint32_t nodes, leaves, max_leaf, depth, max_stack, lights, triangles;
+} pt_bvh_info;
+
+typedef struct pt_device pt_device;          /* one per GPU = one DevicePathTracer        */
+typedef struct pt_host_scene pt_host_scene;  /* HostScene owned by the library            */
+typedef void *pt_stream;                     /* hipStream_t; NULL = the null stream       */
+
+/* ------------------------------------------------------------------------- errors -- */
+PT_API const char *pt_last_error_string(void);
+PT_API const char *pt_version(void);
+
+/* --------------------------------------------------------- per-GPU engine (device) -- */
+/* DevicePathTracer ctor, DevicePathTracer.h:169-192 (cudaSetDevice part). */
+PT_API pt_status pt_device_create(int device_index, pt_device **out);
+/* ~DevicePathTracer, DevicePathTracer.h:372-377 (frees everything, not only the BVH). */
+PT_API pt_status pt_device_destroy(pt_device *dev);
+/* reloadWorld(), DevicePathTracer.h:312-340: copies the scene (no host pointer is kept),
+ * builds the reference-topology BVH and the light list.                                 */
+PT_API pt_status pt_upload_scene(pt_device *dev,
+                                 const pt_triangle *triangles, size_t n_triangles,
+                                 const pt_material *materials, size_t n_materials,
+                                 const pt_texture *textures, size_t n_textures);
+PT_API pt_status pt_upload_host_scene(pt_device *dev, const pt_host_scene *scene);
+/* setFramebuffer(), DevicePathTracer.h:342-358: rgb = 3*w*h bytes, yuv = w*h + 2*(w*h/4)
+ * bytes (Framebuffer.h:27-35), both device-accessible.  No RNG table is allocated: the
+ * per-pixel XORWOW state of render_init (DevicePathTracer.h:46-55) is re-derived in-kernel. */
+PT_API pt_status pt_bind_framebuffer(pt_device *dev, int width, int height,
+                                     uint8_t *rgb_device, uint8_t *yuv_device);
+/* setThreadBlockSize(dim3), DevicePathTracer.h:368: a hint (pixel-tile shape per wave). */
+PT_API pt_status pt_set_thread_block_size(pt_device *dev, unsigned x, unsigned y);
+/* renderTaskAsync(RenderTask&, cudaStream_t), DevicePathTracer.h:194-214: no-op when
+ * task->width == 0; asynchronous on `stream`; camera by value as at :210.               */
+PT_API pt_status pt_render_task_async(pt_device *dev, const pt_task *task,
+                                      const pt_camera *camera, unsigned samples_per_pixel,
+                                      unsigned recursion_depth, pt_stream stream);
+/* synchronizeStream(cudaStream_t), DevicePathTracer.h:222-226. */
+PT_API pt_status pt_stream_sync(pt_device *dev, pt_stream stream);
+/* waitForRenderTask(), DevicePathTracer.h:216-220. */
+PT_API pt_status pt_device_sync(pt_device *dev);
+/* StreamThread.h:19-36: a worker's stream. */
+PT_API pt_status pt_stream_create(pt_device *dev, pt_stream *out);
+PT_API pt_status pt_stream_destroy(pt_device *dev, pt_stream stream);
+
+/* Work counters (new; the metric's numerator).  Read after a sync. */
+PT_API pt_status pt_counters_read(pt_device *dev, pt_counters *out);
+PT_API pt_status pt_counters_reset(pt_device *dev);
+/* Accumulated device time (ms) of the render kernel launches since the last reset,
+ * measured with HIP events on the launch stream; n_launches may be NULL.                */
+PT_API pt_status pt_kernel_time_read(pt_device *dev, double *ms_total, uint64_t *n_launches);
+PT_API pt_status pt_kernel_time_reset(pt_device *dev);
+
+/* BVH introspection (known-answer tests against the oracle).  bounds: 6 floats per node
+ * {x.min,x.max,y.min,y.max,z.min,z.max}; links: 4 u32 per node {left,right,firstTri,triCount}
+ * in the reference's node numbering (bvh.h:11-16, :78-90).                              */
+PT_API pt_status pt_bvh_info_read(pt_device *dev, pt_bvh_info *out);
+PT_API pt_status pt_bvh_copy(pt_device *dev, float *bounds6, uint32_t *links4, int *tri_indices,
+                             int *light_faces);
+
+/* Host-only build of the same BVH (create_world, DevicePathTracer.h:134-146 -> bvh.h:20-176)
+ * without a device: bounds6 / links4 hold up to 2n-1 nodes, tri_indices n entries; any of the
+ * three may be NULL.                                                                      */
+PT_API pt_status pt_host_bvh_build(const pt_triangle *triangles, size_t n_triangles,
+                                   pt_bvh_info *info, float *bounds6, uint32_t *links4,
+                                   int *tri_indices);
+
+/* Framebuffer.h:27-35 replacement for cudaMallocManaged: device-local buffers + explicit
+ * download (the reference relies on UVM page migration as its implicit gather).         */
+PT_API pt_status pt_fb_alloc(pt_device *dev, int width, int height, uint8_t **rgb_device,
+                             uint8_t **yuv_device);
+PT_API pt_status pt_fb_free(pt_device *dev, uint8_t *rgb_device, uint8_t *yuv_device);
+PT_API pt_status pt_fb_download(pt_device *dev, const uint8_t *src_device, uint8_t *dst_host,
+                                size_t bytes, pt_stream stream);
+
+/* Device arithmetic self-test (bit-exactness contract): evaluates on the GPU
+ * op 0: sincos(x)->(out0,out1); 1: a/b; 2: sqrt(a); 3: (float)((double)a / pi);
+ * 4: XORWOW uniform #b (0-based) of seed (uint32)a bits -> out0.                          */
+PT_API pt_status pt_kat_arith(pt_device *dev, int op, const float *a, const float *b,
+                              float *out0, float *out1, size_t n);
+/* Closest hit of n rays through the device traversal: o/d are 3 floats per ray; outputs
+ * t (or -1 on miss) and the face index in the uploaded triangle order (-1 on miss).     */
+PT_API pt_status pt_kat_closest_hit(pt_device *dev, const float *origins, const float *dirs,
+                                    float *t_out, int *face_out, size_t n);
+
+/* --------------------------------------------------------------- scene I/O (host) -- */
+/* SceneLoader::load(std::string&), HostScene.cpp:98-139, for .glb / .gltf-binary input. */
+PT_API pt_status pt_scene_load_glb(const char *path, pt_host_scene **out);
+/* Wavefront OBJ (+ name-prefix material rule of obj_loader.h:65-96 / README.md:60-76). */
+PT_API pt_status pt_scene_load_obj(const char *path, pt_host_scene **out);
+PT_API pt_status pt_scene_create(const pt_triangle *triangles, size_t n_triangles,
+                                 const pt_material *materials, size_t n_materials,
+                                 const pt_texture *textures, size_t n_textures,
+                                 pt_host_scene **out);
+PT_API void      pt_scene_free(pt_host_scene *scene);
+PT_API size_t    pt_scene_triangle_count(const pt_host_scene *scene);
+PT_API size_t    pt_scene_material_count(const pt_host_scene *scene);
+PT_API size_t    pt_scene_texture_count(const pt_host_scene *scene);
+PT_API const pt_triangle *pt_scene_triangles(const pt_host_scene *scene);
+PT_API const pt_material *pt_scene_materials(const pt_host_scene *scene);
+PT_API const pt_texture  *pt_scene_textures(const pt_host_scene *scene);
+PT_API const char *pt_scene_material_name(const pt_host_scene *scene, size_t index);
+/* Benchmark convention for models/cornell_box.glb (BASELINE.md note 1):
+ * (i) zero-emissive materials named diffuse_light* get emissiveFactor (1,1,1);
+ * (ii) exact axis swap (x,y,z) -> (x,z,-y) on every vertex.                             */
+PT_API pt_status pt_scene_apply_cornell_convention(pt_host_scene *scene);
+/* Deterministic synthetic terrain of 2*grid*grid triangles + one emissive quad
+ * (BASELINE.json config 4 uses grid = 2048 -> 8,388,608 + 2 triangles).                 */
+PT_API pt_status pt_scene_make_terrain(unsigned grid, pt_host_scene **out);
+/* Binary PPM (P6) sink for the .glb -> PPM pipeline (README.md:54-58 names build/out.ppm). */
+PT_API pt_status pt_write_ppm(const char *path, int width, int height, const uint8_t *rgb);
+
+/* ------------------------------------------------------------ scheduling (host) ---- */
+/* TaskGenerator::generateEqualTasks(taskCount, taskLayout, w, h), TaskGenerator.h:58-80,
+ * with RenderManager::getTaskLayout(maxTasksInRow), RenderManager.h:42-59 (FSFL).       */
+PT_API pt_status pt_tasks_equal_layout(int task_count, int max_tasks_in_row, int width,
+                                       int height, pt_task *out_tasks);
+/* TaskGenerator::generateEqualTasks(task_count, w, h), TaskGenerator.h:46-55 (one row). */
+PT_API pt_status pt_tasks_equal_row(int task_count, int width, int height, pt_task *out_tasks);
+/* Row-band partition used by the multi-GPU path: the frame is cut into
+ * full-width bands of `band_rows` fb rows (multiple of 2); band b belongs to rank b % n.
+ * Returns the bands of `rank` as tasks (offset_y counted from the image bottom, as
+ * RenderTask does) and their count.                                                     */
+PT_API pt_status pt_tasks_row_bands(int width, int height, int band_rows, int n_ranks, int rank,
+                                    pt_task *out_tasks, int max_tasks, int *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_AMD_H */

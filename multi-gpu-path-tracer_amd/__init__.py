@@ -1,0 +1,18 @@
+"""MI355X-native hot path of 3DevApps/multi-gpu-path-tracer: the per-pixel path-tracing
+megakernel behind the reference's DevicePathTracer / RenderManager / HostScene /
+Framebuffer surface.  All compute lives in libptamd.so (hand-written HIP for gfx950,
+C ABI in include/pt_amd.h); this package is the Python host mirror used by bench.py and
+the tests.  Import it with importlib.import_module("multi-gpu-path-tracer_amd").
+"""
+from . import _capi as capi
+from .host import (CameraConfig, DevicePathTracer, Framebuffer, HostScene, RendererConfig, RenderTask,
+                   Resolution, SceneLoader, FSFL, DSFL, DSDL, host_bvh_build, make_terrain_scene, write_ppm)
+from .scheduling import (RenderManager, TaskGenerator, band_row_ranges, gather_frame, get_task_layout,
+                         pack_bands, packed_size, row_band_tasks, unpack_bands)
+
+__all__ = [
+    "capi", "CameraConfig", "DevicePathTracer", "Framebuffer", "HostScene", "RendererConfig", "RenderTask",
+    "Resolution", "SceneLoader", "FSFL", "DSFL", "DSDL", "host_bvh_build", "make_terrain_scene", "write_ppm",
+    "RenderManager", "TaskGenerator", "band_row_ranges", "gather_frame", "get_task_layout", "pack_bands",
+    "packed_size", "row_band_tasks", "unpack_bands",
+]

@@ -1,0 +1,138 @@
+"""ctypes binding of the C ABI declared in include/pt_amd.h (libptamd.so).
+
+The library is the product: gfx950 kernels + host code.  If it is missing this module raises
+immediately -- there is no Python or CPU fallback for the render path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptamd.so")
+
+PT_OK = 0
+STATUS_NAMES = {
+    0: "PT_OK", 1: "PT_ERR_INVALID", 2: "PT_ERR_HIP", 3: "PT_ERR_NO_LIGHTS", 4: "PT_ERR_STACK",
+    5: "PT_ERR_IO", 6: "PT_ERR_UNSUPPORTED", 7: "PT_ERR_NO_SCENE", 8: "PT_ERR_NO_DEVICE",
+}
+
+# numpy mirrors of the PODs (HostScene.h:28-59, CameraConfig.h:5-17, DevicePathTracer.h:19-25)
+VERTEX_DTYPE = np.dtype([("position", np.float32, 3), ("texCoords", np.float32, 2)])
+TRIANGLE_DTYPE = np.dtype([("v0", VERTEX_DTYPE), ("v1", VERTEX_DTYPE), ("v2", VERTEX_DTYPE),
+                           ("textureIdx", np.int32), ("materialIdx", np.int32)])
+MATERIAL_DTYPE = np.dtype([("baseColor", np.float32, 3), ("baseColorTextureIdx", np.int32),
+                           ("emissiveFactor", np.float32, 3), ("emissiveTextureIdx", np.int32)])
+assert TRIANGLE_DTYPE.itemsize == 68 and MATERIAL_DTYPE.itemsize == 32
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("data", C.POINTER(C.c_float))]
+
+
+class Camera(C.Structure):
+    _fields_ = [("lookFrom", C.c_float * 3), ("front", C.c_float * 3), ("vfov", C.c_float), ("hfov", C.c_float)]
+
+
+class Task(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("offset_x", C.c_int), ("offset_y", C.c_int)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("segments", C.c_uint64), ("box_tests", C.c_uint64),
+                ("tri_tests", C.c_uint64), ("light_tests", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class BvhInfo(C.Structure):
+    _fields_ = [("nodes", C.c_uint32), ("leaves", C.c_uint32), ("max_leaf", C.c_uint32), ("depth", C.c_uint32),
+                ("max_stack", C.c_uint32), ("lights", C.c_uint32), ("triangles", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class PtError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), message))
+        self.status = status
+
+
+_vp = C.c_void_p
+_PROTOS = {
+    # name: (restype, argtypes)
+    "pt_last_error_string": (C.c_char_p, []),
+    "pt_version": (C.c_char_p, []),
+    "pt_device_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "pt_device_destroy": (C.c_int, [_vp]),
+    "pt_upload_scene": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(Texture), C.c_size_t]),
+    "pt_upload_host_scene": (C.c_int, [_vp, _vp]),
+    "pt_bind_framebuffer": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "pt_set_thread_block_size": (C.c_int, [_vp, C.c_uint, C.c_uint]),
+    "pt_render_task_async": (C.c_int, [_vp, C.POINTER(Task), C.POINTER(Camera), C.c_uint, C.c_uint, _vp]),
+    "pt_stream_sync": (C.c_int, [_vp, _vp]),
+    "pt_device_sync": (C.c_int, [_vp]),
+    "pt_stream_create": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "pt_stream_destroy": (C.c_int, [_vp, _vp]),
+    "pt_counters_read": (C.c_int, [_vp, C.POINTER(Counters)]),
+    "pt_counters_reset": (C.c_int, [_vp]),
+    "pt_kernel_time_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "pt_kernel_time_reset": (C.c_int, [_vp]),
+    "pt_bvh_info_read": (C.c_int, [_vp, C.POINTER(BvhInfo)]),
+    "pt_bvh_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pt_host_bvh_build": (C.c_int, [_vp, C.c_size_t, C.POINTER(BvhInfo), _vp, _vp, _vp]),
+    "pt_fb_alloc": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
+    "pt_fb_free": (C.c_int, [_vp, _vp, _vp]),
+    "pt_fb_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "pt_kat_arith": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t]),
+    "pt_kat_closest_hit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_size_t]),
+    "pt_scene_load_glb": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "pt_scene_load_obj": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "pt_scene_create": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(Texture), C.c_size_t, C.POINTER(_vp)]),
+    "pt_scene_free": (None, [_vp]),
+    "pt_scene_triangle_count": (C.c_size_t, [_vp]),
+    "pt_scene_material_count": (C.c_size_t, [_vp]),
+    "pt_scene_texture_count": (C.c_size_t, [_vp]),
+    "pt_scene_triangles": (_vp, [_vp]),
+    "pt_scene_materials": (_vp, [_vp]),
+    "pt_scene_textures": (C.POINTER(Texture), [_vp]),
+    "pt_scene_material_name": (C.c_char_p, [_vp, C.c_size_t]),
+    "pt_scene_apply_cornell_convention": (C.c_int, [_vp]),
+    "pt_scene_make_terrain": (C.c_int, [C.c_uint, C.POINTER(_vp)]),
+    "pt_write_ppm": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vp]),
+    "pt_tasks_equal_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Task)]),
+    "pt_tasks_equal_row": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(Task)]),
+    "pt_tasks_row_bands": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Task), C.c_int,
+                                      C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library; raises if the in-tree build is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). The HIP path is mandatory; there is no fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _PROTOS.items():
+            fn = getattr(handle, name)      # AttributeError = header/library mismatch
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(status):
+    if status != PT_OK:
+        msg = lib().pt_last_error_string()
+        raise PtError(status, msg.decode("utf-8", "replace") if msg else "")
+
+
+def np_ptr(arr):
+    return C.c_void_p(arr.ctypes.data) if arr is not None else None

@@ -1,0 +1,915 @@
+// pt_device.hip -- gfx950 kernels of the hot path and the per-GPU engine behind the C ABI.
+//
+// Replaces, for one GPU, DevicePathTracer (DevicePathTracer.h:167-392) and the kernels it
+// launches: render_init (:46-55, folded into the render kernel), render (:73-120),
+// create_world / create_lights / create_camera (:134-158, done on the host at upload).
+//
+// Kernel shape: one lane = one pixel, one wave64 = one 8x8 pixel tile, 4 waves
+// per workgroup.  Each lane runs a path STATE MACHINE: every trip of the wave loop a live
+// lane traces exactly one ray segment of whatever (sample, bounce) it is on, and rolls
+// straight into its next sample when a path ends, so short paths do not idle behind the
+// longest path of the wave.  The per-lane traversal stack lives in LDS.  No MFMA: this is
+// a divergent gather workload.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "pt_kernels.h"
+
+namespace pt {
+
+// ====================================================================== device code ==
+namespace dev {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+
+struct Hit {
+    float t, u, v;
+    int slot;          // leaf-order triangle slot of the closest hit, -1 = none
+};
+
+// aabb::hit, aabb.h:38-66 (ray_t / rec ignored there too).  inv = 1.0f / direction.
+__device__ __forceinline__ bool box_hit(float xmin, float xmax, float ymin, float ymax, float zmin,
+                                        float zmax, v3 o, v3 inv)
+{
+    float t1 = (xmin - o.x) * inv.x, t2 = (xmax - o.x) * inv.x;
+    float t3 = (ymin - o.y) * inv.y, t4 = (ymax - o.y) * inv.y;
+    float t5 = (zmin - o.z) * inv.z, t6 = (zmax - o.z) * inv.z;
+    float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    return !(tmax < 0) && !(tmin > tmax);
+}
+
+// triangle::hit, triangle.h:63-113 (Moller-Trumbore) on a precomputed (v0, e1, e2) record.
+// Returns true when the candidate is accepted for the interval (tmin, tmax); t/u/v out.
+__device__ __forceinline__ bool tri_hit(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float tmin, float tmax,
+                                        float &t_out, float &u_out, float &v_out)
+{
+    v3 pvec = cross(d, e2);
+    float det = dot(e1, pvec);
+    // triangle.h:78 compares in double against +-1e-8; for a float det that is exactly
+    // |det| <= 1e-8f (1e-8f < 1e-8 < nextafter(1e-8f)).
+    bool ok = !(det <= 1e-8f && det >= -1e-8f);
+    float inv_det = 1.0f / det;                       // :84 (double divide == IEEE 1.0f/det)
+    v3 tvec = o - v0;
+    float u = dot(tvec, pvec) * inv_det;
+    ok = ok && !(u < 0 || u > 1);
+    v3 qvec = cross(tvec, e1);
+    float v = dot(d, qvec) * inv_det;
+    ok = ok && !(v < 0 || u + v > 1);
+    float t = dot(e2, qvec) * inv_det;
+    ok = ok && (t < tmax && t > tmin);
+    t_out = t; u_out = u; v_out = v;
+    return ok;
+}
+
+__device__ __forceinline__ void load_tri(const TriIsect *tris, int slot, v3 &v0, v3 &e1, v3 &e2)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(tris + slot);
+    float4 a = p[0], b = p[1], c = p[2];
+    v0 = mk3(a.x, a.y, a.z);
+    e1 = mk3(a.w, b.x, b.y);
+    e2 = mk3(b.z, b.w, c.x);
+}
+
+// BVH::hit, bvh.h:178-246, in the reference's visit order: both children's boxes, then the
+// left leaf's triangles, then the right leaf's, then descend left-first (the reference's
+// near/far test compares two copies of the same value, :193-196,:230).  No distance
+// pruning on boxes.  `stack` is this lane's LDS column (stride = blockDim.x).
+__device__ __forceinline__ Hit traverse(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
+                                        uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
+{
+    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+    float tmax = tmax0;
+    v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t pair = 0;
+    int sp = 0;
+    while (true) {
+        const float4 *np = reinterpret_cast<const float4 *>(P.nodes + pair);
+        float4 a = np[0], b = np[1], c = np[2];
+        uint4 l = *reinterpret_cast<const uint4 *>(np + 3);
+        bool ol = box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
+        bool orr = box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
+        n_box += 2;
+        // leaf triangles: left range then right range, one Moller-Trumbore per loop trip
+        uint32_t k0 = l.x, n0 = (ol && l.y) ? l.y : 0u;
+        uint32_t k1 = l.z, n1 = (orr && l.w) ? l.w : 0u;
+        if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
+        while (n0 != 0) {
+            v3 v0, e1, e2;
+            load_tri(P.tris, (int)k0, v0, e1, e2);
+            float t, u, v;
+            n_tri++;
+            if (tri_hit(v0, e1, e2, o, d, tmin, tmax, t, u, v)) {
+                tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k0;
+            }
+            k0++; n0--;
+            if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
+        }
+        bool tl = ol && l.y == 0, tr = orr && l.w == 0;
+        if (tl && tr) {
+            stack[sp * stride] = l.z;
+            sp++;
+            pair = l.x;
+        } else if (tl) {
+            pair = l.x;
+        } else if (tr) {
+            pair = l.z;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            pair = stack[sp * stride];
+        }
+    }
+    return h;
+}
+
+// BaseColorTexture::value + pixel_data, Texture.h:30-69.  The reference reads row `height`
+// (one past the end) when j == 0; that row is clamped to height-1 here.
+__device__ __forceinline__ v3 tex_value(const RenderParams &P, int tex, float u, float v)
+{
+    TexDesc td = P.texs[tex];
+    if (td.h <= 0) return mk3((float)242 / 255, (float)45 / 255, (float)27 / 255);
+    u = fmodf(u, 1.0f); v = fmodf(v, 1.0f);
+    int i = (int)(u * (float)td.w);
+    int j = (int)(v * (float)td.h);
+    int x = i < 0 ? 0 : (i < td.w ? i : td.w - 1);
+    int y = j < 0 ? 0 : (j < td.h ? j : td.h - 1);
+    y = td.h - y;
+    if (y > td.h - 1) y = td.h - 1;
+    const float *px = P.texels + td.offset + 3 * ((size_t)y * (size_t)td.w + (size_t)x);
+    double cs = 1.0 / 255.0;
+    return mk3((float)(cs * (double)px[0]), (float)(cs * (double)px[1]), (float)(cs * (double)px[2]));
+}
+
+struct Onb { v3 a0, a1, a2; };
+// onb::onb, onb.h:8-13
+__device__ __forceinline__ Onb onb_make(v3 n)
+{
+    Onb b;
+    b.a2 = normalize(n);
+    v3 a = fabsf(b.a2.x) > 0.9f ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
+    b.a1 = normalize(cross(b.a2, a));
+    b.a0 = cross(b.a2, b.a1);
+    return b;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
+// camera::ray_color (camera.h:49-83) flattened into a per-lane state machine.
+__global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
+{
+    extern __shared__ uint32_t lds_stack[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid / kWave;
+    const int tile = blockIdx.x * kWavesPerBlock + wave;
+    const int tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
+    const int i = tile_x * 8 + (lane & 7), j = tile_y * 8 + (lane >> 3);
+    const bool in_task = (tile_y < P.tiles_y) && (i < P.task_w) && (j < P.task_h);
+    const int x = P.task_ox + i, y = P.task_oy + j;
+    const bool in_frame = in_task && x >= 0 && y >= 0 && x < P.W && y < P.H;
+    const int pixel_index = (P.H - y - 1) * P.W + x;
+    uint32_t *stack = lds_stack + tid;
+
+    xorwow rng;
+    xorwow_init(rng, (uint64_t)(long long)(1984 + pixel_index));     // :54 seed, :80 state copy
+    v3 col = mk3(0.0f, 0.0f, 0.0f);
+    v3 atten = mk3(1.0f, 1.0f, 1.0f);
+    v3 ro = P.cam.origin, rd = mk3(0.0f, 0.0f, 0.0f);
+    uint32_t n_paths = 0, n_seg = 0, n_box = 0, n_tri = 0, n_light = 0;
+    int s = 0;
+    unsigned bounce = 0;
+    bool need_new = true;
+    bool alive = in_frame && P.depth > 0;     // depth 0: ray_color returns (0,0,0) untraced
+
+    while (alive) {
+        if (need_new) {
+            if (s >= P.spp) { alive = false; continue; }
+            // :84-86 + camera::get_ray camera.h:95-97
+            float u = ((float)x + xorwow_uniform(rng)) / (float)(unsigned)P.W;
+            float v = ((float)y + xorwow_uniform(rng)) / (float)(unsigned)P.H;
+            ro = P.cam.origin;
+            rd = ((P.cam.llc + u * P.cam.horizontal) + v * P.cam.vertical) - P.cam.origin;
+            atten = mk3(1.0f, 1.0f, 1.0f);
+            bounce = 0;
+            s++;
+            n_paths++;
+            need_new = false;
+        }
+        n_seg++;
+        Hit h = traverse(P, ro, rd, 0.001f, 3.402823466e+38f, stack, kBlock, n_box, n_tri);
+        if (h.slot < 0) {
+            col = col + mk3(0.0f, 0.0f, 0.0f) * atten;                // camera.h:78-79
+            need_new = true;
+            continue;
+        }
+        // hit_record completion, triangle.h:100-108
+        const float4 *tp = reinterpret_cast<const float4 *>(P.tris + h.slot);
+        float4 tc = tp[2];
+        v3 normal = mk3(tc.y, tc.z, tc.w);
+        v3 p = ro + h.t * rd;
+        const float4 *sp4 = reinterpret_cast<const float4 *>(P.shade + h.slot);
+        float4 s0 = sp4[0], s1 = sp4[1];
+        int mat = __float_as_int(s1.z);
+        const float4 *mp = reinterpret_cast<const float4 *>(P.mats + mat);
+        float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+        int baseTex = __float_as_int(m0.w), emisTex = __float_as_int(m1.w);
+        float tu = 0.0f, tv = 0.0f;
+        if (baseTex >= 0 || emisTex >= 0) {
+            tu = (1 - h.u - h.v) * s0.x + h.u * s0.z + h.v * s1.x;
+            tv = (1 - h.u - h.v) * s0.y + h.u * s0.w + h.v * s1.y;
+        }
+        // UniversalMaterial::emitted, material.h:80-86
+        v3 emitted = mk3(m2.x, m2.y, m2.z);
+        if (emisTex >= 0) emitted = (tex_value(P, emisTex, tu, tv) * mk3(m1.x, m1.y, m1.z)) * 50.0f;
+        if (emitted.x > 0.0001f || emitted.y > 0.0001f || emitted.z > 0.0001f) {   // material.h:63
+            col = col + atten * emitted;                               // camera.h:72-74
+            need_new = true;
+            continue;
+        }
+        // material.h:67-68: a cosine sample that camera.h:65 overwrites; its 2 draws remain.
+        (void)xorwow_next(rng); (void)xorwow_next(rng);
+        v3 albedo = mk3(m0.x, m0.y, m0.z);
+        if (baseTex >= 0) albedo = albedo * tex_value(P, baseTex, tu, tv);
+        Onb uvw = onb_make(normal);                                    // cosine_pdf ctor, pdf.h:15-17
+        v3 dir;
+        if (xorwow_uniform(rng) < 0.5f) {                              // mixture_pdf::generate, pdf.h:66-72
+            float uu = xorwow_uniform(rng);                            // hitable_list::random, hitable_list.h:23-26
+            int idx = (int)truncf((float)((double)uu * P.light_index_scale));
+            const float4 *lp = reinterpret_cast<const float4 *>(P.lights + idx);
+            float4 la = lp[0], ld = lp[3], le = lp[4];
+            float r1 = xorwow_uniform(rng), r2 = xorwow_uniform(rng);  // triangle::random, triangle.h:41-47
+            float sq = sqrtf(r1);
+            v3 lv0 = mk3(la.x, la.y, la.z), lv1 = mk3(ld.x, ld.y, ld.z), lv2 = mk3(ld.w, le.x, le.y);
+            v3 rp = ((1 - sq) * lv0 + (sq * (1 - r2)) * lv1) + (sq * r2) * lv2;
+            dir = rp - p;
+        } else {
+            float r1 = xorwow_uniform(rng), r2 = xorwow_uniform(rng);  // random_cosine_direction, helper_math.h:1519-1527
+            float z = sqrtf(1 - r2);
+            float phi = (float)(2 * M_PI * (double)r1);
+            float sn, cs;
+            pt_sincosf(phi, sn, cs);
+            float sq2 = sqrtf(r2);
+            float lx = cs * 2 * sq2, ly = sn * 2 * sq2;
+            dir = (lx * uvw.a0 + ly * uvw.a1) + z * uvw.a2;            // onb::local, onb.h:20-22
+        }
+        // hitable_list::pdf_value, hitable_list.h:16-22 -> triangle::pdf_value, triangle.h:32-40
+        float lsum = 0.0f;
+        for (int k = 0; k < P.n_lights; k++) {
+            const float4 *lp = reinterpret_cast<const float4 *>(P.lights + k);
+            float4 la = lp[0], lb = lp[1], lc = lp[2], le = lp[4];
+            v3 v0 = mk3(la.x, la.y, la.z), e1 = mk3(la.w, lb.x, lb.y), e2 = mk3(lb.z, lb.w, lc.x);
+            v3 ln = mk3(lc.y, lc.z, lc.w);
+            float t, u, v;
+            n_light++;
+            float pdfv = 0.0f;
+            if (tri_hit(v0, e1, e2, p, dir, 0.001f, 3.402823466e+38f, t, u, v)) {
+                float distance_squared = t * t * dot(dir, dir);
+                float cosine = fabsf(dot(dir, ln) / length(dir));
+                pdfv = distance_squared / (cosine * le.z);
+            }
+            lsum += P.light_weight * pdfv;
+        }
+        v3 ndir = normalize(dir);
+        float cosv = dot(ndir, uvw.a2);                                // cosine_pdf::value, pdf.h:19-22
+        float cpdf = (cosv <= 0) ? 0.0f : (float)((double)cosv / M_PI);
+        float pdf_value = 0.5f * lsum + 0.5f * cpdf;                   // mixture_pdf::value, pdf.h:63-65
+        float cos2 = dot(normal, ndir);                                // scattering_pdf, material.h:88-91
+        float spdf = cos2 < 0 ? 0.0f : (float)((double)cos2 / M_PI);
+        atten = atten * ((albedo * spdf) / pdf_value);                 // camera.h:69
+        ro = p; rd = dir;
+        bounce++;
+        if (bounce >= P.depth) {
+            col = col + mk3(0.0f, 0.0f, 0.0f);                         // camera.h:82
+            need_new = true;
+        }
+    }
+
+    if (in_frame) {
+        // :98-119
+        v3 q = (255.99f * col) / (float)P.spp;
+        int cr = f2i_rz_sat(q.x * 1.0f), cg = f2i_rz_sat(q.y * 1.0f), cb = f2i_rz_sat(q.z * 1.0f);
+        cr = min(255, cr); cg = min(255, cg); cb = min(255, cb);
+        P.rgb[3 * (size_t)pixel_index] = (uint8_t)cr;
+        P.rgb[3 * (size_t)pixel_index + 1] = (uint8_t)cg;
+        P.rgb[3 * (size_t)pixel_index + 2] = (uint8_t)cb;
+        P.yuv[pixel_index] = (uint8_t)(((66 * cr + 129 * cg + 25 * cb + 128) >> 8) + 16);
+        int blockRow = pixel_index / P.W, blockCol = pixel_index % P.W;
+        if (blockRow % 2 == 0 && blockCol % 2 == 0) {
+            int total = P.W * P.H, uvSize = total / 4;
+            int uvIndex = (blockRow / 2) * (P.W / 2) + (blockCol / 2);
+            P.yuv[total + uvIndex] = (uint8_t)(((-38 * cr - 74 * cg + 112 * cb + 128) >> 8) + 128);
+            P.yuv[total + uvSize + uvIndex] = (uint8_t)(((112 * cr - 94 * cg - 18 * cb + 128) >> 8) + 128);
+        }
+    }
+    // exact work counters: one atomic per wave per counter
+    uint32_t c0 = wave_sum(n_paths), c1 = wave_sum(n_seg), c2 = wave_sum(n_box), c3 = wave_sum(n_tri),
+             c4 = wave_sum(n_light);
+    if (lane == 0 && (c0 | c1)) {
+        atomicAdd(&P.counters[0], (unsigned long long)c0);
+        atomicAdd(&P.counters[1], (unsigned long long)c1);
+        atomicAdd(&P.counters[2], (unsigned long long)c2);
+        atomicAdd(&P.counters[3], (unsigned long long)c3);
+        atomicAdd(&P.counters[4], (unsigned long long)c4);
+    }
+}
+
+// ---- known-answer kernels (bit-exactness contract) -----------------------------------
+__global__ void kat_arith_kernel(int op, const float *a, const float *b, float *o0, float *o1, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r0 = 0.0f, r1 = 0.0f;
+    switch (op) {
+    case 0: pt_sincosf(a[i], r0, r1); break;
+    case 1: r0 = a[i] / b[i]; break;
+    case 2: r0 = sqrtf(a[i]); break;
+    case 3: r0 = (float)((double)a[i] / M_PI); break;
+    case 4: {
+        xorwow st;
+        xorwow_init(st, (uint64_t)__float_as_uint(a[i]));
+        unsigned skip = __float_as_uint(b[i]);
+        for (unsigned k = 0; k < skip; k++) (void)xorwow_next(st);
+        r0 = xorwow_uniform(st);
+        break;
+    }
+    default: break;
+    }
+    o0[i] = r0;
+    if (o1) o1[i] = r1;
+}
+
+__global__ void kat_hit_kernel(RenderParams P, const float *org, const float *dir, float *t_out,
+                               int *face_out, size_t n)
+{
+    extern __shared__ uint32_t lds_stack[];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = i < n;
+    size_t k = live ? i : 0;
+    v3 o = mk3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
+    v3 d = mk3(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
+    uint32_t nb = 0, nt = 0;
+    Hit h = traverse(P, o, d, 0.001f, 3.402823466e+38f, lds_stack + threadIdx.x, (int)blockDim.x, nb, nt);
+    if (live) {
+        t_out[i] = h.slot >= 0 ? h.t : -1.0f;
+        int face = -1;
+        if (h.slot >= 0) face = P.shade[h.slot].face;
+        face_out[i] = face;
+    }
+}
+
+} // namespace dev
+
+// ======================================================================== host code ==
+
+// camera::recalculate_camera_params, camera.h:21-36: uniform per launch, so it runs on the
+// host (the reference recomputes it in every thread for every sample, racing on one object).
+CameraBasis camera_basis(const pt_camera &cfg)
+{
+    CameraBasis cam;
+    v3 from = mk3(cfg.lookFrom[0], cfg.lookFrom[1], cfg.lookFrom[2]);
+    v3 front = mk3(cfg.front[0], cfg.front[1], cfg.front[2]);
+    v3 lookAt = from + front;
+    float theta_v = (float)((double)cfg.vfov * M_PI / 180);
+    float half_height = pt_tanf(theta_v / 2);
+    float theta_h = (float)((double)cfg.hfov * M_PI / 180);
+    float half_width = pt_tanf(theta_h / 2);
+    v3 vup = mk3(0.0f, 1.0f, 0.0f);
+    v3 w = normalize(from - lookAt);
+    v3 u = normalize(cross(vup, w));
+    v3 v = cross(w, u);
+    cam.origin = from;
+    cam.llc = ((from - half_width * u) - half_height * v) - w;
+    cam.horizontal = (2 * half_width) * u;
+    cam.vertical = (2 * half_height) * v;
+    return cam;
+}
+
+} // namespace pt
+
+using namespace pt;
+
+#define PT_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return set_error(PT_ERR_HIP, std::string("HIP ERROR = ") + std::to_string((int)e_) + \
+                                             " (" + hipGetErrorString(e_) + ") at " + __FILE__ +  \
+                                             ":" + std::to_string(__LINE__) + " '" #call "'");   \
+    } while (0)
+
+struct pt_device {
+    int index = 0;
+    // scene (device)
+    NodePair *d_nodes = nullptr;
+    TriIsect *d_tris = nullptr;
+    TriShade *d_shade = nullptr;
+    LightRec *d_lights = nullptr;
+    MatRec *d_mats = nullptr;
+    TexDesc *d_texs = nullptr;
+    float *d_texels = nullptr;
+    unsigned long long *d_counters = nullptr;
+    bool has_scene = false;
+    int n_lights = 0;
+    // scene (host mirrors for introspection)
+    RefBvh bvh;
+    std::vector<int> light_faces;
+    size_t n_tris = 0;
+    // framebuffer binding
+    int W = 0, H = 0;
+    uint8_t *rgb = nullptr, *yuv = nullptr;
+    unsigned block_x = 8, block_y = 8;
+    // kernel timing
+    std::mutex mu;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_events;
+    double ms_total = 0.0;
+    uint64_t launches = 0;
+};
+
+static void free_scene(pt_device *d)
+{
+    (void)hipFree(d->d_nodes); (void)hipFree(d->d_tris); (void)hipFree(d->d_shade);
+    (void)hipFree(d->d_lights); (void)hipFree(d->d_mats); (void)hipFree(d->d_texs);
+    (void)hipFree(d->d_texels);
+    d->d_nodes = nullptr; d->d_tris = nullptr; d->d_shade = nullptr; d->d_lights = nullptr;
+    d->d_mats = nullptr; d->d_texs = nullptr; d->d_texels = nullptr;
+    d->has_scene = false;
+}
+
+template <typename T>
+static pt_status upload_vec(const std::vector<T> &v, T **out)
+{
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    PT_HIP(hipMalloc((void **)out, bytes));
+    if (!v.empty()) PT_HIP(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+static pt_status drain_events(pt_device *d)
+{
+    for (auto &pr : d->pending) {
+        float ms = 0.0f;
+        PT_HIP(hipEventSynchronize(pr.second));
+        PT_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        d->ms_total += (double)ms;
+        d->launches++;
+        d->free_events.push_back(pr);
+    }
+    d->pending.clear();
+    return PT_OK;
+}
+
+extern "C" {
+
+pt_status pt_device_create(int device_index, pt_device **out)
+{
+    clear_error();
+    if (!out) return set_error(PT_ERR_INVALID, "null out pointer");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_error(PT_ERR_NO_DEVICE, "no HIP device visible: the gfx950 kernels are mandatory, there is no CPU fallback");
+    if (device_index < 0 || device_index >= count) return set_error(PT_ERR_INVALID, "device index out of range");
+    PT_HIP(hipSetDevice(device_index));
+    std::unique_ptr<pt_device> d(new pt_device());
+    d->index = device_index;
+    PT_HIP(hipMalloc((void **)&d->d_counters, 8 * sizeof(unsigned long long)));
+    PT_HIP(hipMemset(d->d_counters, 0, 8 * sizeof(unsigned long long)));
+    *out = d.release();
+    return PT_OK;
+}
+
+pt_status pt_device_destroy(pt_device *dev)
+{
+    clear_error();
+    if (!dev) return PT_OK;
+    (void)hipSetDevice(dev->index);
+    (void)hipDeviceSynchronize();
+    free_scene(dev);
+    (void)hipFree(dev->d_counters);
+    for (auto &pr : dev->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto &pr : dev->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    delete dev;
+    return PT_OK;
+}
+
+pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, const pt_material *mats,
+                          size_t m, const pt_texture *texs, size_t k)
+{
+    clear_error();
+    if (!dev || !tris || !mats || n == 0 || m == 0 || (k && !texs))
+        return set_error(PT_ERR_INVALID, "scene needs at least one triangle and one material");
+    if (n > (size_t)1 << 30) return set_error(PT_ERR_INVALID, "too many triangles");
+    PT_HIP(hipSetDevice(dev->index));
+    PT_HIP(hipDeviceSynchronize());
+
+    // loadMaterials, DevicePathTracer.h:267-291, incl. the texture-pointer inheritance quirk
+    // (:269-279: the two pointers are declared outside the loop and never reset).
+    std::vector<MatRec> mrec(m);
+    int baseTex = -1, emisTex = -1;
+    for (size_t i = 0; i < m; i++) {
+        if (mats[i].baseColorTextureIdx >= 0) baseTex = mats[i].baseColorTextureIdx;
+        if (mats[i].emissiveTextureIdx >= 0) emisTex = mats[i].emissiveTextureIdx;
+        if (baseTex >= (int)k || emisTex >= (int)k) return set_error(PT_ERR_INVALID, "material texture index out of range");
+        MatRec &r = mrec[i];
+        r.br = mats[i].baseColor[0]; r.bg = mats[i].baseColor[1]; r.bb = mats[i].baseColor[2];
+        r.er = mats[i].emissiveFactor[0]; r.eg = mats[i].emissiveFactor[1]; r.eb = mats[i].emissiveFactor[2];
+        r.baseTex = baseTex; r.emisTex = emisTex;
+        r.e50r = r.er * 50.0f; r.e50g = r.eg * 50.0f; r.e50b = r.eb * 50.0f;      // material.h:85
+        r.is_light = (r.e50r > 0.0001f || r.e50g > 0.0001f || r.e50b > 0.0001f) ? 1 : 0;
+    }
+    // loadTextures, DevicePathTracer.h:241-265: all texels in one pool
+    std::vector<TexDesc> tdesc(k);
+    std::vector<float> pool;
+    for (size_t i = 0; i < k; i++) {
+        if (texs[i].width < 0 || texs[i].height < 0) return set_error(PT_ERR_INVALID, "negative texture size");
+        size_t cnt = (size_t)texs[i].width * (size_t)texs[i].height * 3;
+        if (cnt && !texs[i].data) return set_error(PT_ERR_INVALID, "texture without data");
+        tdesc[i].w = texs[i].width; tdesc[i].h = texs[i].height;
+        tdesc[i].offset = (uint32_t)pool.size(); tdesc[i].pad = 0;
+        pool.insert(pool.end(), texs[i].data, texs[i].data + cnt);
+    }
+    // loadTrianglesWithTextures, DevicePathTracer.h:293-309: faces + light list in face order
+    std::vector<float> pos(9 * n);
+    std::vector<int> lights;
+    for (size_t i = 0; i < n; i++) {
+        if (tris[i].materialIdx < 0 || (size_t)tris[i].materialIdx >= m)
+            return set_error(PT_ERR_INVALID, "triangle material index out of range");
+        memcpy(&pos[9 * i], tris[i].v0.position, 12);
+        memcpy(&pos[9 * i + 3], tris[i].v1.position, 12);
+        memcpy(&pos[9 * i + 6], tris[i].v2.position, 12);
+        const float *e = mats[tris[i].materialIdx].emissiveFactor;
+        if (e[0] > 0.0001f || e[1] > 0.0001f || e[2] > 0.0001f) lights.push_back((int)i);   // :305
+    }
+    if (lights.empty())
+        return set_error(PT_ERR_NO_LIGHTS, "scene has no emissive face: the reference's light sampling dereferences an empty list (hitable_list.h:23-26)");
+
+    // create_world, DevicePathTracer.h:134-146 -> BVH::BVH, bvh.h:20-33, on the host
+    RefBvh bvh;
+    build_reference_bvh(pos.data(), n, bvh);
+    if (bvh.max_stack > 64)
+        return set_error(PT_ERR_STACK, "BVH needs more than the reference's 64 traversal-stack entries (bvh.h:179)");
+
+    // flatten: inner nodes -> NodePair records, triangles -> leaf order
+    std::vector<uint32_t> pair_of(bvh.nodes.size(), 0xFFFFFFFFu);
+    uint32_t n_pairs = 0;
+    for (size_t i = 0; i < bvh.nodes.size(); i++) if (bvh.nodes[i].triCount == 0) pair_of[i] = n_pairs++;
+    bool root_leaf = bvh.nodes[0].triCount != 0;
+    std::vector<NodePair> pairs(root_leaf ? 1 : n_pairs);
+    auto fill_child = [&](const RefNode &c, uint32_t ci, float *box6, uint32_t &link, uint32_t &cnt) {
+        box6[0] = c.xmin; box6[1] = c.xmax; box6[2] = c.ymin; box6[3] = c.ymax; box6[4] = c.zmin; box6[5] = c.zmax;
+        cnt = c.triCount;
+        link = c.triCount ? c.firstTri : pair_of[ci];
+    };
+    auto fill_pair = [&](NodePair &p, uint32_t li, uint32_t ri) {
+        float lb[6], rb[6];
+        fill_child(bvh.nodes[li], li, lb, p.llink, p.lcnt);
+        fill_child(bvh.nodes[ri], ri, rb, p.rlink, p.rcnt);
+        p.lxmin = lb[0]; p.lxmax = lb[1]; p.lymin = lb[2]; p.lymax = lb[3]; p.lzmin = lb[4]; p.lzmax = lb[5];
+        p.rxmin = rb[0]; p.rxmax = rb[1]; p.rymin = rb[2]; p.rymax = rb[3]; p.rzmin = rb[4]; p.rzmax = rb[5];
+    };
+    if (root_leaf) {
+        // bvh.h:26,:189-190: an unsplit root has left = right = 0, i.e. it is its own two children.
+        fill_pair(pairs[0], 0, 0);
+    } else {
+        for (size_t i = 0; i < bvh.nodes.size(); i++)
+            if (bvh.nodes[i].triCount == 0) fill_pair(pairs[pair_of[i]], bvh.nodes[i].left, bvh.nodes[i].right);
+    }
+    std::vector<TriIsect> isect(n);
+    std::vector<TriShade> shade(n);
+    auto make_isect = [&](const pt_triangle &t, float *out12, float *area, float *v1v2) {
+        v3 v0 = mk3(t.v0.position[0], t.v0.position[1], t.v0.position[2]);
+        v3 v1 = mk3(t.v1.position[0], t.v1.position[1], t.v1.position[2]);
+        v3 v2 = mk3(t.v2.position[0], t.v2.position[1], t.v2.position[2]);
+        v3 e1 = v1 - v0, e2 = v2 - v0;                     // triangle.h:66-67
+        v3 cr = cross(e1, e2);
+        v3 nn = normalize(cr);                             // triangle.h:102
+        out12[0] = v0.x; out12[1] = v0.y; out12[2] = v0.z; out12[3] = e1.x; out12[4] = e1.y; out12[5] = e1.z;
+        out12[6] = e2.x; out12[7] = e2.y; out12[8] = e2.z; out12[9] = nn.x; out12[10] = nn.y; out12[11] = nn.z;
+        if (area) *area = length(cr) * 0.5f;               // triangle.h:28
+        if (v1v2) { v1v2[0] = v1.x; v1v2[1] = v1.y; v1v2[2] = v1.z; v1v2[3] = v2.x; v1v2[4] = v2.y; v1v2[5] = v2.z; }
+    };
+    for (size_t s = 0; s < n; s++) {
+        int face = bvh.indices[s];
+        const pt_triangle &t = tris[face];
+        make_isect(t, &isect[s].v0x, nullptr, nullptr);
+        TriShade &sh = shade[s];
+        sh.u0 = t.v0.texCoords[0]; sh.v0 = t.v0.texCoords[1];
+        sh.u1 = t.v1.texCoords[0]; sh.v1 = t.v1.texCoords[1];
+        sh.u2 = t.v2.texCoords[0]; sh.v2 = t.v2.texCoords[1];
+        sh.material = t.materialIdx; sh.face = face;
+    }
+    std::vector<LightRec> lrec(lights.size());
+    for (size_t i = 0; i < lights.size(); i++) {
+        float v1v2[6];
+        make_isect(tris[lights[i]], &lrec[i].v0x, &lrec[i].area, v1v2);
+        lrec[i].v1x = v1v2[0]; lrec[i].v1y = v1v2[1]; lrec[i].v1z = v1v2[2];
+        lrec[i].v2x = v1v2[3]; lrec[i].v2y = v1v2[4]; lrec[i].v2z = v1v2[5];
+        lrec[i].pad = 0.0f;
+    }
+
+    free_scene(dev);
+    pt_status st;
+    if ((st = upload_vec(pairs, &dev->d_nodes)) != PT_OK) return st;
+    if ((st = upload_vec(isect, &dev->d_tris)) != PT_OK) return st;
+    if ((st = upload_vec(shade, &dev->d_shade)) != PT_OK) return st;
+    if ((st = upload_vec(lrec, &dev->d_lights)) != PT_OK) return st;
+    if ((st = upload_vec(mrec, &dev->d_mats)) != PT_OK) return st;
+    if ((st = upload_vec(tdesc, &dev->d_texs)) != PT_OK) return st;
+    if ((st = upload_vec(pool, &dev->d_texels)) != PT_OK) return st;
+    dev->bvh = std::move(bvh);
+    dev->light_faces = lights;
+    dev->n_lights = (int)lights.size();
+    dev->n_tris = n;
+    dev->has_scene = true;
+    return PT_OK;
+}
+
+pt_status pt_upload_host_scene(pt_device *dev, const pt_host_scene *scene)
+{
+    if (!scene) { clear_error(); return set_error(PT_ERR_INVALID, "null scene"); }
+    const HostSceneImpl &s = host_scene_impl(scene);
+    return pt_upload_scene(dev, s.triangles.data(), s.triangles.size(), s.materials.data(),
+                           s.materials.size(), s.textures.data(), s.textures.size());
+}
+
+pt_status pt_bind_framebuffer(pt_device *dev, int width, int height, uint8_t *rgb, uint8_t *yuv)
+{
+    clear_error();
+    if (!dev || width <= 0 || height <= 0 || !rgb || !yuv) return set_error(PT_ERR_INVALID, "bad framebuffer");
+    if ((long long)width * (long long)height > (1ll << 30)) return set_error(PT_ERR_INVALID, "framebuffer too large");
+    if ((width | height) & 1)
+        return set_error(PT_ERR_UNSUPPORTED, "odd framebuffer sizes: the reference's YUV420 indexing (DevicePathTracer.h:107-119) writes past its planes; only even widths and heights are accepted");
+    dev->W = width; dev->H = height; dev->rgb = rgb; dev->yuv = yuv;
+    return PT_OK;
+}
+
+pt_status pt_set_thread_block_size(pt_device *dev, unsigned x, unsigned y)
+{
+    clear_error();
+    if (!dev || x == 0 || y == 0) return set_error(PT_ERR_INVALID, "bad thread block size");
+    dev->block_x = x; dev->block_y = y;     // hint only: waves always cover 8x8 pixel tiles
+    return PT_OK;
+}
+
+static pt_status fill_params(pt_device *dev, RenderParams &P)
+{
+    P.nodes = dev->d_nodes; P.tris = dev->d_tris; P.shade = dev->d_shade; P.lights = dev->d_lights;
+    P.mats = dev->d_mats; P.texs = dev->d_texs; P.texels = dev->d_texels;
+    P.rgb = dev->rgb; P.yuv = dev->yuv; P.counters = dev->d_counters;
+    P.n_lights = dev->n_lights;
+    P.light_weight = 1.0f / (float)dev->n_lights;                        // hitable_list.h:17
+    P.light_index_scale = (double)(dev->n_lights - 1) + 0.999999;        // hitable_list.h:24
+    P.W = dev->W; P.H = dev->H;
+    P.stack_entries = (int)std::max<uint32_t>(dev->bvh.max_stack, 2) - 1;
+    return PT_OK;
+}
+
+pt_status pt_render_task_async(pt_device *dev, const pt_task *task, const pt_camera *camera,
+                               unsigned spp, unsigned depth, pt_stream stream)
+{
+    clear_error();
+    if (!dev || !task || !camera) return set_error(PT_ERR_INVALID, "null argument");
+    if (task->width == 0) return PT_OK;                                  // DevicePathTracer.h:195-196
+    if (!dev->has_scene || !dev->rgb) return set_error(PT_ERR_NO_SCENE, "render before pt_upload_scene / pt_bind_framebuffer");
+    if (task->width < 0 || task->height <= 0 || spp > (1u << 24))
+        return set_error(PT_ERR_INVALID, "bad task rectangle or sample count");
+    // host-side shape check before launching a hand-written kernel
+    if (task->offset_x < 0 || task->offset_y < 0 || task->offset_x + task->width > dev->W ||
+        task->offset_y + task->height > dev->H)
+        return set_error(PT_ERR_INVALID, "task rectangle leaves the framebuffer");
+    PT_HIP(hipSetDevice(dev->index));                                    // :200
+    RenderParams P;
+    fill_params(dev, P);
+    P.cam = camera_basis(*camera);
+    P.task_w = task->width; P.task_h = task->height; P.task_ox = task->offset_x; P.task_oy = task->offset_y;
+    P.tiles_x = (task->width + 7) / 8; P.tiles_y = (task->height + 7) / 8;
+    P.spp = (int)spp; P.depth = depth;
+    long long tiles = (long long)P.tiles_x * P.tiles_y;
+    unsigned blocks = (unsigned)((tiles + dev::kWavesPerBlock - 1) / dev::kWavesPerBlock);
+    size_t lds = (size_t)P.stack_entries * dev::kBlock * sizeof(uint32_t);
+    hipStream_t hs = (hipStream_t)stream;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    {
+        std::lock_guard<std::mutex> lk(dev->mu);
+        if (!dev->free_events.empty()) { ev = dev->free_events.back(); dev->free_events.pop_back(); }
+        else { PT_HIP(hipEventCreate(&ev.first)); PT_HIP(hipEventCreate(&ev.second)); }
+    }
+    PT_HIP(hipEventRecord(ev.first, hs));
+    hipLaunchKernelGGL(dev::render_kernel, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipEventRecord(ev.second, hs));
+    {
+        std::lock_guard<std::mutex> lk(dev->mu);
+        dev->pending.push_back(ev);
+    }
+    return PT_OK;
+}
+
+pt_status pt_stream_sync(pt_device *dev, pt_stream stream)
+{
+    clear_error();
+    if (!dev) return set_error(PT_ERR_INVALID, "null device");
+    PT_HIP(hipSetDevice(dev->index));
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return PT_OK;
+}
+
+pt_status pt_device_sync(pt_device *dev)
+{
+    clear_error();
+    if (!dev) return set_error(PT_ERR_INVALID, "null device");
+    PT_HIP(hipSetDevice(dev->index));
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipDeviceSynchronize());
+    return PT_OK;
+}
+
+pt_status pt_stream_create(pt_device *dev, pt_stream *out)
+{
+    clear_error();
+    if (!dev || !out) return set_error(PT_ERR_INVALID, "null argument");
+    PT_HIP(hipSetDevice(dev->index));
+    hipStream_t s;
+    PT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (pt_stream)s;
+    return PT_OK;
+}
+
+pt_status pt_stream_destroy(pt_device *dev, pt_stream stream)
+{
+    clear_error();
+    if (!dev) return set_error(PT_ERR_INVALID, "null device");
+    PT_HIP(hipSetDevice(dev->index));
+    if (stream) PT_HIP(hipStreamDestroy((hipStream_t)stream));
+    return PT_OK;
+}
+
+pt_status pt_counters_read(pt_device *dev, pt_counters *out)
+{
+    clear_error();
+    if (!dev || !out) return set_error(PT_ERR_INVALID, "null argument");
+    PT_HIP(hipSetDevice(dev->index));
+    unsigned long long h[8];
+    PT_HIP(hipMemcpy(h, dev->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    out->paths = h[0]; out->segments = h[1]; out->box_tests = h[2]; out->tri_tests = h[3]; out->light_tests = h[4];
+    return PT_OK;
+}
+
+pt_status pt_counters_reset(pt_device *dev)
+{
+    clear_error();
+    if (!dev) return set_error(PT_ERR_INVALID, "null device");
+    PT_HIP(hipSetDevice(dev->index));
+    PT_HIP(hipDeviceSynchronize());
+    PT_HIP(hipMemset(dev->d_counters, 0, 8 * sizeof(unsigned long long)));
+    return PT_OK;
+}
+
+pt_status pt_kernel_time_read(pt_device *dev, double *ms_total, uint64_t *n_launches)
+{
+    clear_error();
+    if (!dev || !ms_total) return set_error(PT_ERR_INVALID, "null argument");
+    PT_HIP(hipSetDevice(dev->index));
+    std::lock_guard<std::mutex> lk(dev->mu);
+    pt_status st = drain_events(dev);
+    if (st != PT_OK) return st;
+    *ms_total = dev->ms_total;
+    if (n_launches) *n_launches = dev->launches;
+    return PT_OK;
+}
+
+pt_status pt_kernel_time_reset(pt_device *dev)
+{
+    clear_error();
+    if (!dev) return set_error(PT_ERR_INVALID, "null device");
+    PT_HIP(hipSetDevice(dev->index));
+    std::lock_guard<std::mutex> lk(dev->mu);
+    pt_status st = drain_events(dev);
+    if (st != PT_OK) return st;
+    dev->ms_total = 0.0; dev->launches = 0;
+    return PT_OK;
+}
+
+pt_status pt_bvh_info_read(pt_device *dev, pt_bvh_info *out)
+{
+    clear_error();
+    if (!dev || !out) return set_error(PT_ERR_INVALID, "null argument");
+    if (!dev->has_scene) return set_error(PT_ERR_NO_SCENE, "no scene uploaded");
+    out->nodes = (uint32_t)dev->bvh.nodes.size(); out->leaves = dev->bvh.leaves; out->max_leaf = dev->bvh.max_leaf;
+    out->depth = dev->bvh.depth; out->max_stack = dev->bvh.max_stack; out->lights = (uint32_t)dev->n_lights;
+    out->triangles = (uint32_t)dev->n_tris;
+    return PT_OK;
+}
+
+pt_status pt_bvh_copy(pt_device *dev, float *bounds6, uint32_t *links4, int *tri_indices, int *light_faces)
+{
+    clear_error();
+    if (!dev) return set_error(PT_ERR_INVALID, "null device");
+    if (!dev->has_scene) return set_error(PT_ERR_NO_SCENE, "no scene uploaded");
+    for (size_t i = 0; i < dev->bvh.nodes.size(); i++) {
+        const RefNode &n = dev->bvh.nodes[i];
+        if (bounds6) { float *b = bounds6 + 6 * i; b[0] = n.xmin; b[1] = n.xmax; b[2] = n.ymin; b[3] = n.ymax; b[4] = n.zmin; b[5] = n.zmax; }
+        if (links4) { uint32_t *l = links4 + 4 * i; l[0] = n.left; l[1] = n.right; l[2] = n.firstTri; l[3] = n.triCount; }
+    }
+    if (tri_indices) memcpy(tri_indices, dev->bvh.indices.data(), sizeof(int) * dev->n_tris);
+    if (light_faces) memcpy(light_faces, dev->light_faces.data(), sizeof(int) * dev->light_faces.size());
+    return PT_OK;
+}
+
+pt_status pt_fb_alloc(pt_device *dev, int width, int height, uint8_t **rgb, uint8_t **yuv)
+{
+    clear_error();
+    if (!dev || width <= 0 || height <= 0 || !rgb || !yuv) return set_error(PT_ERR_INVALID, "bad argument");
+    PT_HIP(hipSetDevice(dev->index));
+    size_t total = (size_t)width * (size_t)height;
+    PT_HIP(hipMalloc((void **)rgb, total * 3));
+    PT_HIP(hipMalloc((void **)yuv, total + 2 * (total / 4)));
+    PT_HIP(hipMemset(*rgb, 0, total * 3));
+    PT_HIP(hipMemset(*yuv, 0, total + 2 * (total / 4)));
+    return PT_OK;
+}
+
+pt_status pt_fb_free(pt_device *dev, uint8_t *rgb, uint8_t *yuv)
+{
+    clear_error();
+    if (!dev) return set_error(PT_ERR_INVALID, "null device");
+    PT_HIP(hipSetDevice(dev->index));
+    if (dev->rgb == rgb) { dev->rgb = nullptr; dev->yuv = nullptr; }
+    if (rgb) PT_HIP(hipFree(rgb));
+    if (yuv) PT_HIP(hipFree(yuv));
+    return PT_OK;
+}
+
+pt_status pt_fb_download(pt_device *dev, const uint8_t *src, uint8_t *dst, size_t bytes, pt_stream stream)
+{
+    clear_error();
+    if (!dev || !src || !dst) return set_error(PT_ERR_INVALID, "null argument");
+    PT_HIP(hipSetDevice(dev->index));
+    PT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    PT_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return PT_OK;
+}
+
+pt_status pt_kat_arith(pt_device *dev, int op, const float *a, const float *b, float *out0, float *out1, size_t n)
+{
+    clear_error();
+    if (!dev || !a || !out0 || op < 0 || op > 4) return set_error(PT_ERR_INVALID, "bad argument");
+    if (n == 0) return PT_OK;
+    PT_HIP(hipSetDevice(dev->index));
+    float *da = nullptr, *db = nullptr, *d0 = nullptr, *d1 = nullptr;
+    size_t bytes = n * sizeof(float);
+    PT_HIP(hipMalloc((void **)&da, bytes)); PT_HIP(hipMalloc((void **)&db, bytes));
+    PT_HIP(hipMalloc((void **)&d0, bytes)); PT_HIP(hipMalloc((void **)&d1, bytes));
+    PT_HIP(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    if (b) PT_HIP(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice)); else PT_HIP(hipMemset(db, 0, bytes));
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(dev::kat_arith_kernel, dim3(blocks), dim3(256), 0, 0, op, da, db, d0, d1, n);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipDeviceSynchronize());
+    PT_HIP(hipMemcpy(out0, d0, bytes, hipMemcpyDeviceToHost));
+    if (out1) PT_HIP(hipMemcpy(out1, d1, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(d0); (void)hipFree(d1);
+    return PT_OK;
+}
+
+pt_status pt_kat_closest_hit(pt_device *dev, const float *org, const float *dirs, float *t_out, int *face_out, size_t n)
+{
+    clear_error();
+    if (!dev || !org || !dirs || !t_out || !face_out) return set_error(PT_ERR_INVALID, "null argument");
+    if (!dev->has_scene) return set_error(PT_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return PT_OK;
+    PT_HIP(hipSetDevice(dev->index));
+    RenderParams P;
+    memset(&P, 0, sizeof P);
+    fill_params(dev, P);
+    float *dorg = nullptr, *ddir = nullptr, *dt = nullptr; int *df = nullptr;
+    PT_HIP(hipMalloc((void **)&dorg, n * 12)); PT_HIP(hipMalloc((void **)&ddir, n * 12));
+    PT_HIP(hipMalloc((void **)&dt, n * 4)); PT_HIP(hipMalloc((void **)&df, n * 4));
+    PT_HIP(hipMemcpy(dorg, org, n * 12, hipMemcpyHostToDevice));
+    PT_HIP(hipMemcpy(ddir, dirs, n * 12, hipMemcpyHostToDevice));
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
+    hipLaunchKernelGGL(dev::kat_hit_kernel, dim3(blocks), dim3(256), lds, 0, P, dorg, ddir, dt, df, n);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipDeviceSynchronize());
+    PT_HIP(hipMemcpy(t_out, dt, n * 4, hipMemcpyDeviceToHost));
+    PT_HIP(hipMemcpy(face_out, df, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dorg); (void)hipFree(ddir); (void)hipFree(dt); (void)hipFree(df);
+    return PT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,89 @@
+// pt_internal.h -- host-side internals shared by the C-ABI translation units.
+#pragma once
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_amd.h"
+#include "pt_math.h"
+
+namespace pt {
+
+// Thread-local error message behind pt_last_error_string().
+pt_status set_error(pt_status code, const std::string &msg);
+void clear_error();
+
+// HostScene.h:55-59 HostScene, owning its storage; exposed through the pt_scene_* C ABI.
+struct HostSceneImpl {
+    std::vector<pt_triangle> triangles;
+    std::vector<pt_material> materials;
+    std::vector<std::string> material_names;
+    std::vector<std::vector<float>> texel_storage;   // float3 texels per texture
+    std::vector<pt_texture> textures;                // views into texel_storage
+    void rebuild_texture_views();
+};
+} // namespace pt
+struct pt_host_scene;
+namespace pt {
+const HostSceneImpl &host_scene_impl(const pt_host_scene *s);
+
+// Reference-topology BVH (bvh.h:11-176) as built on the host, in the reference's node
+// numbering, plus the statistics the C ABI reports.
+struct RefNode {
+    float xmin, xmax, ymin, ymax, zmin, zmax;
+    uint32_t left, right, firstTri, triCount;
+};
+struct RefBvh {
+    std::vector<RefNode> nodes;       // nodesUsed entries
+    std::vector<int> indices;         // triangle permutation (first n entries of bvh.h:22)
+    uint32_t leaves = 0, max_leaf = 0, depth = 0, max_stack = 0;
+};
+// positions: 9 floats per triangle (v0,v1,v2); centroid computed as triangle.h:27.
+void build_reference_bvh(const float *positions9, size_t n_tris, RefBvh &out);
+
+// ------------------------------------------------------------- device-side layout --
+// All records are multiples of 16 B so a lane fetches them with dwordx4 loads.
+//
+// NodePair (64 B), one per INNER reference node, root = pair 0.  A visit of the reference
+// traversal (bvh.h:190-243) reads exactly one pair: both children's boxes and what each
+// child is.  For child c: cnt == 0 -> inner, link = its pair index; cnt > 0 -> leaf,
+// link = first slot in the leaf-ordered triangle array.
+struct NodePair {
+    float lxmin, lxmax, lymin, lymax;
+    float lzmin, lzmax, rxmin, rxmax;
+    float rymin, rymax, rzmin, rzmax;
+    uint32_t llink, lcnt, rlink, rcnt;
+};
+// TriIsect (48 B), in leaf order (slot k = reference indices[k]): everything
+// triangle::hit needs, with e1, e2 and normalize(cross(e1,e2)) precomputed -- pure
+// functions of the vertices, so bit-identical to evaluating them per test
+// (triangle.h:66-67, :102).
+struct TriIsect {
+    float v0x, v0y, v0z, e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z, nx, ny, nz;
+};
+// TriShade (32 B), leaf order: fetched once per accepted closest hit.
+struct TriShade {
+    float u0, v0, u1, v1, u2, v2;
+    int32_t material;
+    int32_t face;                     // index in the uploaded triangle order
+};
+// LightRec (80 B), light-list order (DevicePathTracer.h:304-307).
+struct LightRec {
+    float v0x, v0y, v0z, e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z, nx, ny, nz;
+    float v1x, v1y, v1z, v2x;
+    float v2y, v2z, area, pad;
+};
+// MatRec (48 B).
+struct MatRec {
+    float br, bg, bb; int32_t baseTex;          // baseColorFactor_, baseColorTexture_ (-1 = null)
+    float er, eg, eb; int32_t emisTex;          // emissiveFactor_, emissiveTexture_
+    float e50r, e50g, e50b; int32_t is_light;   // emissiveFactor_*50 (material.h:85)
+};
+struct TexDesc { int32_t w, h; uint32_t offset /* in floats */, pad; };
+
+} // namespace pt

@@ -1,0 +1,39 @@
+// pt_kernels.h -- launch parameter block shared by pt_device.hip's host and device code.
+#pragma once
+
+#include <stdint.h>
+
+#include "pt_internal.h"
+
+namespace pt {
+
+struct CameraBasis {          // camera.h:21-36, evaluated once per launch on the host
+    v3 origin, llc, horizontal, vertical;
+};
+
+struct RenderParams {
+    const NodePair *nodes;
+    const TriIsect *tris;
+    const TriShade *shade;
+    const LightRec *lights;
+    const MatRec *mats;
+    const TexDesc *texs;
+    const float *texels;
+    uint8_t *rgb;
+    uint8_t *yuv;
+    unsigned long long *counters;     // 5 x u64: paths, segments, box, tri, light
+    CameraBasis cam;
+    double light_index_scale;         // (n-1) + 0.999999, hitable_list.h:24
+    float light_weight;               // 1.0f / n, hitable_list.h:17
+    int n_lights;
+    int W, H;                         // Resolution
+    int task_w, task_h, task_ox, task_oy;
+    int tiles_x, tiles_y;             // 8x8 pixel tiles covering the task
+    int spp;
+    unsigned depth;
+    int stack_entries;                // per-lane LDS stack slots (max_stack - 1)
+};
+
+CameraBasis camera_basis(const pt_camera &cfg);
+
+} // namespace pt

@@ -1,0 +1,118 @@
+// pt_math.h -- arithmetic contract of the hot path, shared by the product's host code
+// (camera set-up, BVH build) and its gfx950 kernels.  Product code: never includes oracle/.
+//
+// Contract (DESIGN.md "Arithmetic contract"): every + - * / sqrt below is ONE correctly
+// rounded IEEE-754 operation in the order the reference's source text prescribes
+// (helper_math.h operators), compiled with -ffp-contract=off; rsqrtf(x) = 1.0f/sqrtf(x)
+// (helper_math.h:80-83); sin/cos/tan = pt_sincosf (explicit fmaf polynomial).
+#pragma once
+
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PT_HD __host__ __device__ __forceinline__
+#else
+#define PT_HD inline
+#endif
+
+#if defined(__FAST_MATH__)
+#error "the path tracer's arithmetic contract forbids -ffast-math"
+#endif
+
+namespace pt {
+
+struct v3 { float x, y, z; };
+
+PT_HD v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_HD v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_HD v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_HD v3 operator*(v3 a, v3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_HD v3 operator*(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+PT_HD v3 operator*(float s, v3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+PT_HD v3 operator/(v3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }   // helper_math.h:1015
+PT_HD float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }      // :1266
+PT_HD v3 cross(v3 a, v3 b)
+{
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+PT_HD float length(v3 v) { return sqrtf(dot(v, v)); }                           // :1309
+PT_HD v3 normalize(v3 v)                                                        // :1327 + :80
+{
+    float inv = 1.0f / sqrtf(dot(v, v));
+    return v * inv;
+}
+
+// sin/cos for 0 <= x <= 2*pi(+): Cody-Waite reduction by pi/2 with fmaf, Cephes
+// single-precision minimax polynomials on [-pi/4, pi/4]; stands in for CUDA's cosf/sinf
+// (helper_math.h:1524-1525) and tan (camera.h:25,27).  Bit-identical on x86-64 and gfx950.
+PT_HD void pt_sincosf(float x, float &s, float &c)
+{
+    float kf = (float)(int)(x * 0.636619772f + 0.5f);
+    int k = (int)kf;
+    float r = fmaf(-kf, 1.57079637e+0f, x);
+    r = fmaf(-kf, -4.37113883e-8f, r);
+    float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    float sr = fmaf(ps * z, r, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    float cr = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    int q = k & 3;
+    float s0 = (q & 1) ? cr : sr;
+    float c0 = (q & 1) ? sr : cr;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q == 1) || (q == 2)) ? -c0 : c0;
+}
+PT_HD float pt_tanf(float x)
+{
+    float s, c;
+    pt_sincosf(x, s, c);
+    return s / c;
+}
+
+// cuRAND XORWOW as used by the reference (curand_init(seed,0,0) DevicePathTracer.h:54,
+// curand_uniform at every call site listed in SURVEY.md 8c-1).  State is re-derived from
+// the seed in-kernel instead of being read from a 48 B/pixel table.
+struct xorwow { uint32_t d, v0, v1, v2, v3, v4; };
+
+PT_HD void xorwow_init(xorwow &st, uint64_t seed)
+{
+    uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u;
+    uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0;
+    uint32_t t1 = 2591861531u * s1;
+    st.d = 6615241u + t1 + t0;
+    st.v0 = 123456789u + t0;
+    st.v1 = 362436069u ^ t0;
+    st.v2 = 521288629u + t1;
+    st.v3 = 88675123u ^ t1;
+    st.v4 = 5783321u + t0;
+}
+PT_HD uint32_t xorwow_next(xorwow &st)
+{
+    uint32_t t = st.v0 ^ (st.v0 >> 2);
+    st.v0 = st.v1; st.v1 = st.v2; st.v2 = st.v3; st.v3 = st.v4;
+    st.v4 = (st.v4 ^ (st.v4 << 4)) ^ (t ^ (t << 1));
+    st.d += 362437u;
+    return st.v4 + st.d;
+}
+// curand_uniform: x * 2^-32 + 2^-33 in (0, 1]
+PT_HD float xorwow_uniform(xorwow &st)
+{
+    return (float)xorwow_next(st) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+
+// float -> int with CUDA cvt.rzi.s32.f32 semantics (truncate, saturate, NaN -> 0), which
+// is also what gfx950's v_cvt_i32_f32 does; spelled out so the host agrees.
+PT_HD int f2i_rz_sat(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)f;
+}
+
+} // namespace pt

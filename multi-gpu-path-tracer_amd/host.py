@@ -1,0 +1,356 @@
+"""Python face of the reference's plug-in surface for the hot path, over the C ABI.
+
+Names, argument meaning and error behaviour follow the reference's C++ classes so that the
+parity tests read like tests of the reference:
+
+  SceneLoader.load / HostScene      HostScene.h:55-82, HostScene.cpp:98-139
+  CameraConfig                      CameraConfig.h:5-17
+  Resolution / RendererConfig       RendererConfig.h:6-37
+  RenderTask                        DevicePathTracer.h:19-25
+  Framebuffer                       Framebuffer.h:6-89
+  DevicePathTracer                  DevicePathTracer.h:167-392
+
+torch supplies device memory and streams only; all compute is in libptamd.so.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _capi as capi
+
+
+# ----------------------------------------------------------------------------- scene --
+class HostScene:
+    """HostScene (HostScene.h:55-59): triangles, textures, materials, owned by the library."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+
+    def __del__(self):
+        try:
+            if self._h:
+                capi.lib().pt_scene_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def from_arrays(triangles: np.ndarray, materials: np.ndarray, textures: Optional[List[np.ndarray]] = None):
+        tris = np.ascontiguousarray(triangles, dtype=capi.TRIANGLE_DTYPE)
+        mats = np.ascontiguousarray(materials, dtype=capi.MATERIAL_DTYPE)
+        textures = textures or []
+        keep = [np.ascontiguousarray(t, dtype=np.float32) for t in textures]
+        tex = (capi.Texture * max(len(keep), 1))()
+        for i, t in enumerate(keep):
+            assert t.ndim == 3 and t.shape[2] == 3, "texture must be [height, width, 3] float texels (0..255)"
+            tex[i].height, tex[i].width = t.shape[0], t.shape[1]
+            tex[i].data = t.ctypes.data_as(C.POINTER(C.c_float))
+        out = C.c_void_p()
+        capi.check(capi.lib().pt_scene_create(capi.np_ptr(tris), len(tris), capi.np_ptr(mats), len(mats),
+                                              tex, len(keep), C.byref(out)))
+        return HostScene(out.value)
+
+    @property
+    def triangles(self) -> np.ndarray:
+        n = capi.lib().pt_scene_triangle_count(self._h)
+        ptr = capi.lib().pt_scene_triangles(self._h)
+        buf = (C.c_char * (n * capi.TRIANGLE_DTYPE.itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=capi.TRIANGLE_DTYPE).copy()
+
+    @property
+    def materials(self) -> np.ndarray:
+        n = capi.lib().pt_scene_material_count(self._h)
+        ptr = capi.lib().pt_scene_materials(self._h)
+        buf = (C.c_char * (n * capi.MATERIAL_DTYPE.itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=capi.MATERIAL_DTYPE).copy()
+
+    @property
+    def material_names(self) -> List[str]:
+        n = capi.lib().pt_scene_material_count(self._h)
+        return [capi.lib().pt_scene_material_name(self._h, i).decode() for i in range(n)]
+
+    @property
+    def textures(self) -> List[np.ndarray]:
+        n = capi.lib().pt_scene_texture_count(self._h)
+        arr = capi.lib().pt_scene_textures(self._h)
+        out = []
+        for i in range(n):
+            w, h = arr[i].width, arr[i].height
+            out.append(np.ctypeslib.as_array(arr[i].data, shape=(h, w, 3)).copy())
+        return out
+
+    def applyCornellConvention(self):
+        """Benchmark convention for models/cornell_box.glb."""
+        capi.check(capi.lib().pt_scene_apply_cornell_convention(self._h))
+        return self
+
+
+class SceneLoader:
+    """SceneLoader::load(std::string&), HostScene.cpp:98-139 (.glb); .obj via the C ABI too."""
+
+    def load(self, path: str) -> HostScene:
+        out = C.c_void_p()
+        fn = capi.lib().pt_scene_load_obj if path.lower().endswith(".obj") else capi.lib().pt_scene_load_glb
+        if not (path.lower().endswith(".obj") or path.lower().endswith(".glb") or path.lower().endswith(".gltf")):
+            raise RuntimeError("Unsupported file type" + path)          # HostScene.cpp:134
+        try:
+            capi.check(fn(path.encode(), C.byref(out)))
+        except capi.PtError as e:
+            raise RuntimeError(str(e))                                   # loader throws std::runtime_error
+        return HostScene(out.value)
+
+
+def make_terrain_scene(grid: int) -> HostScene:
+    out = C.c_void_p()
+    capi.check(capi.lib().pt_scene_make_terrain(grid, C.byref(out)))
+    return HostScene(out.value)
+
+
+def write_ppm(path: str, rgb: np.ndarray):
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = rgb.shape[0], rgb.shape[1]
+    capi.check(capi.lib().pt_write_ppm(path.encode(), w, h, capi.np_ptr(rgb)))
+
+
+# ---------------------------------------------------------------------------- configs --
+@dataclass
+class CameraConfig:
+    """CameraConfig.h:5-17."""
+    lookFrom: Tuple[float, float, float]
+    front: Tuple[float, float, float]
+    vfov: float = 45.0
+    hfov: float = 45.0
+
+    def as_c(self) -> capi.Camera:
+        c = capi.Camera()
+        c.lookFrom[:] = [float(v) for v in self.lookFrom]
+        c.front[:] = [float(v) for v in self.front]
+        c.vfov, c.hfov = float(self.vfov), float(self.hfov)
+        return c
+
+
+@dataclass
+class Resolution:
+    width: int = 400
+    height: int = 400
+
+
+FSFL, DSFL, DSDL = 0, 1, 2   # SchedulingAlgorithmType, RendererConfig.h:12-17
+
+
+@dataclass
+class RendererConfig:
+    """RendererConfig.h:19-37 defaults."""
+    jobId: str = "0"
+    samplesPerPixel: int = 10
+    recursionDepth: int = 3
+    modelPath: str = ""
+    gpuNumber: int = 1
+    streamsPerGpu: int = 1
+    resolution: Resolution = field(default_factory=Resolution)
+    algorithmType: int = FSFL
+    threadBlockSize: Tuple[int, int] = (8, 8)
+    vfov: float = 45.0
+    hfov: float = 45.0
+    maxTasksInRow: int = 2
+    showTasks: bool = True
+    kParam: int = 1
+
+
+@dataclass
+class RenderTask:
+    """DevicePathTracer.h:19-25."""
+    width: int
+    height: int
+    offset_x: int
+    offset_y: int
+    time: int = 0
+
+    def as_c(self) -> capi.Task:
+        return capi.Task(self.width, self.height, self.offset_x, self.offset_y)
+
+
+# ------------------------------------------------------------------------ framebuffer --
+class Framebuffer:
+    """Framebuffer.h:6-89 without managed memory: RGB (3 B/px) and planar YUV420 buffers
+    live in HBM as torch uint8 tensors; hosts read them after an explicit copy."""
+
+    def __init__(self, res: Resolution, device="cuda:0"):
+        import torch
+        self._torch = torch
+        self.device = torch.device(device)
+        self.resolution_ = Resolution(0, 0)
+        self.rgb = None
+        self.yuv = None
+        self.setResolution(res)
+
+    def setResolution(self, res: Resolution):
+        if self.rgb is not None and res.width == self.resolution_.width and res.height == self.resolution_.height:
+            return
+        total = res.width * res.height
+        self.rgb = self._torch.zeros(total * 3, dtype=self._torch.uint8, device=self.device)
+        self.yuv = self._torch.zeros(total + 2 * (total // 4), dtype=self._torch.uint8, device=self.device)
+        self.resolution_ = Resolution(res.width, res.height)
+
+    def getResolution(self) -> Resolution:
+        return self.resolution_
+
+    def getPixelCount(self) -> int:
+        return self.resolution_.width * self.resolution_.height
+
+    def getRGBPtr(self) -> int:
+        return self.rgb.data_ptr()
+
+    def getYUVPtr(self) -> int:
+        return self.yuv.data_ptr()
+
+    def rgb_host(self) -> np.ndarray:
+        return self.rgb.cpu().numpy().reshape(self.resolution_.height, self.resolution_.width, 3)
+
+    def yuv_host(self) -> np.ndarray:
+        return self.yuv.cpu().numpy()
+
+
+# ------------------------------------------------------------------ per-GPU engine ----
+class DevicePathTracer:
+    """DevicePathTracer (DevicePathTracer.h:167-392) on one MI355X through the C ABI."""
+
+    def __init__(self, device_idx: int, samplesPerPixel: int, recursionDepth: int, threadBlockSize,
+                 hostScene: HostScene, framebuffer: Framebuffer, cameraConfig: CameraConfig):
+        self.device_idx_ = device_idx
+        self.samplesPerPixel_ = samplesPerPixel
+        self.recursionDepth_ = recursionDepth
+        self.threadBlockSize_ = tuple(threadBlockSize)
+        self.hostScene_ = hostScene
+        self.cameraConfig_ = cameraConfig
+        self.framebuffer_ = None
+        h = C.c_void_p()
+        capi.check(capi.lib().pt_device_create(device_idx, C.byref(h)))
+        self._h = h
+        capi.check(capi.lib().pt_set_thread_block_size(self._h, *self.threadBlockSize_))
+        self.reloadWorld()
+        self.reloadCamera()
+        self.setFramebuffer(framebuffer)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.lib().pt_device_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- DevicePathTracer.h:194-226
+    def renderTaskAsync(self, task: RenderTask, stream=None):
+        cam = self.cameraConfig_.as_c()
+        t = task.as_c()
+        capi.check(capi.lib().pt_render_task_async(self._h, C.byref(t), C.byref(cam), self.samplesPerPixel_,
+                                                   self.recursionDepth_, _stream_ptr(stream)))
+
+    def waitForRenderTask(self):
+        capi.check(capi.lib().pt_device_sync(self._h))
+
+    def synchronizeStream(self, stream=None):
+        capi.check(capi.lib().pt_stream_sync(self._h, _stream_ptr(stream)))
+
+    # -- mutators, DevicePathTracer.h:230-370
+    def reloadCamera(self):
+        pass   # the camera basis is derived from cameraConfig_ at every launch (by value, :210)
+
+    def reloadWorld(self):
+        capi.check(capi.lib().pt_upload_host_scene(self._h, self.hostScene_._h))
+
+    def setFramebuffer(self, framebuffer: Framebuffer):
+        self.framebuffer_ = framebuffer
+        res = framebuffer.getResolution()
+        capi.check(capi.lib().pt_bind_framebuffer(self._h, res.width, res.height,
+                                                  C.c_void_p(framebuffer.getRGBPtr()),
+                                                  C.c_void_p(framebuffer.getYUVPtr())))
+
+    def setSamplesPerPixel(self, samplesPerPixel: int):
+        self.samplesPerPixel_ = samplesPerPixel
+
+    def setRecursionDepth(self, recursionDepth: int):
+        self.recursionDepth_ = recursionDepth
+
+    def setThreadBlockSize(self, threadBlockSize):
+        self.threadBlockSize_ = tuple(threadBlockSize)
+        capi.check(capi.lib().pt_set_thread_block_size(self._h, *self.threadBlockSize_))
+
+    # -- additions: exact work counters and kernel time (the metric's inputs)
+    def readCounters(self) -> dict:
+        c = capi.Counters()
+        capi.check(capi.lib().pt_counters_read(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def resetCounters(self):
+        capi.check(capi.lib().pt_counters_reset(self._h))
+
+    def kernelTime(self) -> Tuple[float, int]:
+        ms = C.c_double()
+        n = C.c_uint64()
+        capi.check(capi.lib().pt_kernel_time_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def resetKernelTime(self):
+        capi.check(capi.lib().pt_kernel_time_reset(self._h))
+
+    def bvhInfo(self) -> dict:
+        info = capi.BvhInfo()
+        capi.check(capi.lib().pt_bvh_info_read(self._h, C.byref(info)))
+        return info.as_dict()
+
+    def bvhCopy(self):
+        info = self.bvhInfo()
+        bounds = np.zeros((info["nodes"], 6), np.float32)
+        links = np.zeros((info["nodes"], 4), np.uint32)
+        idx = np.zeros(info["triangles"], np.int32)
+        lights = np.zeros(info["lights"], np.int32)
+        capi.check(capi.lib().pt_bvh_copy(self._h, capi.np_ptr(bounds), capi.np_ptr(links), capi.np_ptr(idx),
+                                          capi.np_ptr(lights)))
+        return bounds, links, idx, lights
+
+    def katArith(self, op: int, a: np.ndarray, b: Optional[np.ndarray] = None):
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32) if b is not None else None
+        o0 = np.zeros_like(a)
+        o1 = np.zeros_like(a)
+        capi.check(capi.lib().pt_kat_arith(self._h, op, capi.np_ptr(a), capi.np_ptr(b), capi.np_ptr(o0),
+                                           capi.np_ptr(o1), a.size))
+        return o0, o1
+
+    def katClosestHit(self, origins: np.ndarray, dirs: np.ndarray):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        t = np.zeros(len(o), np.float32)
+        f = np.zeros(len(o), np.int32)
+        capi.check(capi.lib().pt_kat_closest_hit(self._h, capi.np_ptr(o), capi.np_ptr(d), capi.np_ptr(t),
+                                                 capi.np_ptr(f), len(o)))
+        return t, f
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    return C.c_void_p(stream.cuda_stream)     # torch.cuda.Stream
+
+
+def host_bvh_build(triangles: np.ndarray):
+    """Host-only build of the reference-topology BVH (no GPU needed)."""
+    tris = np.ascontiguousarray(triangles, dtype=capi.TRIANGLE_DTYPE)
+    n = len(tris)
+    info = capi.BvhInfo()
+    bounds = np.zeros((2 * n - 1, 6), np.float32)
+    links = np.zeros((2 * n - 1, 4), np.uint32)
+    idx = np.zeros(n, np.int32)
+    capi.check(capi.lib().pt_host_bvh_build(capi.np_ptr(tris), n, C.byref(info), capi.np_ptr(bounds),
+                                            capi.np_ptr(links), capi.np_ptr(idx)))
+    k = info.nodes
+    return info.as_dict(), bounds[:k], links[:k], idx

@@ -1,0 +1,735 @@
+/*
+ * pt_oracle.c -- CPU restatement of the reference's per-pixel path-tracing hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under multi-gpu-path-tracer_amd/ (the product) may
+ * include, link, import or execute this file.  Its only callers are tests/,
+ * __graft_entry__.smoke() (as the checker) and bench.py's `cpu_baseline` leg.
+ *
+ * PARITY STATUS: **parity unpinned** at the image level.
+ *   - The reference (3DevApps/multi-gpu-path-tracer) ships no tests, golden images or
+ *     known-answer vectors for this path, and its integrator is
+ *     __device__-only CUDA that cannot be built in this image without writing stand-in
+ *     headers for cuda_runtime.h / curand_kernel.h / thrust / assimp / glm (forbidden), so
+ *     there is no oracle/_ref build.
+ *   - cuRAND XORWOW (CUDA toolkit, not in the reference tree) is restated from the
+ *     published Marsaglia step + the recalled curand_kernel.h seeding constants
+ *     (SURVEY.md 8c-1); CUDA libm cosf/sinf/tanf/rsqrtf and nvcc's FMA contraction are
+ *     unpinnable without NVIDIA hardware.  The arithmetic contract restated here is
+ *     therefore: every + - * / sqrt is a single correctly-rounded IEEE-754 binary32 (or,
+ *     where the reference's source text promotes to double, binary64) operation, evaluated
+ *     in source order with NO contraction; rsqrtf(x) = 1.0f/sqrtf(x) (the reference's own
+ *     host definition, helper_math.h:80-83); cosf/sinf/tanf = the explicit fmaf polynomial
+ *     `ptor_sincosf` below (<= ~1.5 ulp), which the HIP kernel implements independently.
+ *   - What IS pinned: the survey-stage probe of the reference headers recorded structural
+ *     statistics (BVH node/leaf counts, max leaf, depth, segments
+ *     per path, box/triangle tests per segment); tests/test_oracle_pins.py checks this
+ *     restatement against those.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/src).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no -ffast-math).
+ */
+#include <math.h>
+#include <float.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#if defined(__FAST_MATH__)
+#error "pt_oracle.c must not be built with -ffast-math"
+#endif
+
+/* ------------------------------------------------------------------ data model ---- */
+/* HostScene.h:28-59 (Vertex, Triangle, HostMaterial, HostTexture), flattened to C PODs.
+ * A texture index of -1 stands for an empty std::optional<int>.                          */
+typedef struct { float px, py, pz; float u, v; } ptor_vertex;            /* Vertex, 20 B   */
+typedef struct { ptor_vertex v0, v1, v2; int textureIdx; int materialIdx; } ptor_triangle;
+typedef struct {
+    float baseColor[3];  int baseColorTextureIdx;
+    float emissive[3];   int emissiveTextureIdx;
+} ptor_material;
+typedef struct { int width, height; const float *data; /* float3 texels, 0..255 */ } ptor_texture;
+
+/* CameraConfig.h:5-17 (front, lookFrom, vfov, hfov; pitch/yaw unused on this path). */
+typedef struct { float lookFrom[3]; float front[3]; float vfov, hfov; } ptor_camera;
+/* DevicePathTracer.h:19-25 RenderTask (time omitted). */
+typedef struct { int width, height, offset_x, offset_y; } ptor_task;
+
+typedef struct {
+    uint64_t paths;        /* camera rays started                                        */
+    uint64_t segments;     /* BVH::hit calls from camera::ray_color (camera.h:55)        */
+    uint64_t box_tests;    /* aabb::hit calls                                            */
+    uint64_t tri_tests;    /* triangle::hit calls from BVH::hit                          */
+    uint64_t light_tests;  /* triangle::hit calls from triangle::pdf_value               */
+    uint64_t rng_draws;    /* curand_uniform calls                                       */
+    uint64_t max_stack;    /* deepest BVH::hit stack use (entries, incl. sentinel)       */
+    uint64_t nan_pixels;   /* pixels whose accumulated colour has a NaN channel          */
+} ptor_counters;
+
+typedef struct { float x, y, z; } f3;
+
+static inline f3 mk3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+/* helper_math.h float3 operators: all component-wise, one IEEE op per component. */
+static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+static inline f3 div3s(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); } /* :1015 */
+/* helper_math.h:1266-1269 */
+static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* helper_math.h cross (quoted in SURVEY a-11) */
+static inline f3 cross3(f3 a, f3 b)
+{
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* helper_math.h:1309-1312 */
+static inline float length3(f3 v) { return sqrtf(dot3(v, v)); }
+/* helper_math.h:1327-1331 normalize = v * rsqrtf(dot(v,v)); rsqrtf = 1.0f/sqrtf (:80-83) */
+static inline f3 normalize3(f3 v)
+{
+    float inv = 1.0f / sqrtf(dot3(v, v));
+    return scale3(v, inv);
+}
+/* CUDA fminf/fmaxf = IEEE minNum/maxNum (a NaN operand is ignored); C99 fminf/fmaxf agree. */
+
+/* ---------------------------------------------------------- sin/cos/tan contract ---- */
+/*
+ * Stand-in for CUDA libm cosf/sinf (helper_math.h:1524-1525) and tan (camera.h:25,27):
+ * Cody-Waite reduction by pi/2 with fmaf, Cephes single-precision minimax polynomials on
+ * [-pi/4, pi/4], every step an explicit fmaf / mul / add so that host and gfx950 agree
+ * bit-for-bit.  Domain used by the path: 0 <= x <= 2*pi (+1 ulp).
+ */
+void ptor_sincosf(float x, float *s_out, float *c_out)
+{
+    float kf = (float)(int)(x * 0.636619772f + 0.5f);   /* nearest multiple of pi/2, x >= 0 */
+    int   k  = (int)kf;
+    float r  = fmaf(-kf, 1.57079637e+0f, x);            /* pi/2 hi (0x3FC90FDB)            */
+    r        = fmaf(-kf, -4.37113883e-8f, r);           /* pi/2 lo                         */
+    float z  = r * r;
+    /* sin(r) = r + r*z*(S0 + z*(S1 + z*S2)) */
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps       = fmaf(ps, z, -1.6666654611e-1f);
+    float sr = fmaf(ps * z, r, r);
+    /* cos(r) = 1 - z/2 + z*z*(C0 + z*(C1 + z*C2)) */
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc       = fmaf(pc, z, 4.166664568298827e-2f);
+    float cr = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    float s, c;
+    switch (k & 3) {
+    case 0:  s =  sr; c =  cr; break;
+    case 1:  s =  cr; c = -sr; break;
+    case 2:  s = -sr; c = -cr; break;
+    default: s = -cr; c =  sr; break;
+    }
+    *s_out = s; *c_out = c;
+}
+static inline float ptor_tanf(float x)
+{
+    float s, c; ptor_sincosf(x, &s, &c); return s / c;
+}
+
+/* ----------------------------------------------------------------- cuRAND XORWOW ---- */
+/* curand_init(seed, 0, 0, &state) / curand_uniform(&state): CUDA toolkit curand_kernel.h
+ * (not in the reference tree; constants recalled).  Call sites:
+ * DevicePathTracer.h:54 (init), :84-85, hitable_list.h:24, triangle.h:42-43, pdf.h:67,
+ * helper_math.h:1520-1521.                                                                */
+typedef struct { uint32_t d; uint32_t v[5]; } ptor_rng;
+
+void ptor_xorwow_init(ptor_rng *st, uint64_t seed)
+{
+    uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u;
+    uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0;
+    uint32_t t1 = 2591861531u * s1;
+    st->d    = 6615241u + t1 + t0;
+    st->v[0] = 123456789u + t0;
+    st->v[1] = 362436069u ^ t0;
+    st->v[2] = 521288629u + t1;
+    st->v[3] = 88675123u ^ t1;
+    st->v[4] = 5783321u + t0;
+    /* subsequence 0, offset 0: no skip-ahead */
+}
+uint32_t ptor_xorwow_next(ptor_rng *st)
+{
+    uint32_t t = st->v[0] ^ (st->v[0] >> 2);
+    st->v[0] = st->v[1]; st->v[1] = st->v[2]; st->v[2] = st->v[3]; st->v[3] = st->v[4];
+    st->v[4] = (st->v[4] ^ (st->v[4] << 4)) ^ (t ^ (t << 1));
+    st->d += 362437u;
+    return st->v[4] + st->d;
+}
+/* curand_uniform: x * 2^-32 + 2^-33, result in (0, 1]. */
+static inline float ptor_uniform_from(uint32_t x)
+{
+    return (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+
+/* -------------------------------------------------------------- device-side scene ---- */
+typedef struct {                      /* triangle.h:14-61 as built by the host ctor :17-29 */
+    f3 v0, v1, v2;
+    float uv0[2], uv1[2], uv2[2];
+    float area;                       /* :28 */
+    f3 centroid;                      /* :27 */
+    int mat;                          /* mat_ptr_ as an index */
+} otri;
+
+typedef struct {                      /* bvh.h:11-16 BVHNode (isLeaf is never set/read) */
+    float xmin, xmax, ymin, ymax, zmin, zmax;   /* aabb = 3 intervals {min,max} */
+    uint32_t left, right, firstTri, triCount;
+} onode;
+
+typedef struct {                      /* material.h:40-102 UniversalMaterial, ptrs -> idx */
+    f3 baseColor;  int baseTex;       /* -1 = nullptr */
+    f3 emissive;   int emisTex;
+} omat;
+
+typedef struct { int w, h; float *data; } otex;
+
+typedef struct ptor_scene {
+    otri  *tris;   int ntris;
+    omat  *mats;   int nmats;
+    otex  *texs;   int ntexs;
+    int   *lights; int nlights;       /* face indices, DevicePathTracer.h:304-307 */
+    onode *nodes;  uint32_t nodesUsed;
+    int   *indices;
+} ptor_scene;
+
+/* ------------------------------------------------------------------- aabb / bvh ---- */
+/* aabb.h:12-14 + :90-96 + interval.h:6,14-17: default box = [0,0]^3 padded by delta/2. */
+static void box_default(onode *n)
+{
+    float delta = 0.00001;            /* aabb.h:92: double literal -> float */
+    float padding = delta / 2;        /* interval.h:15 */
+    n->xmin = 0.0f - padding; n->xmax = 0.0f + padding;
+    n->ymin = 0.0f - padding; n->ymax = 0.0f + padding;
+    n->zmin = 0.0f - padding; n->zmax = 0.0f + padding;
+}
+/* aabb.h:80-88 */
+static void box_extend(onode *n, f3 v)
+{
+    n->xmin = fminf(v.x, n->xmin); n->ymin = fminf(v.y, n->ymin); n->zmin = fminf(v.z, n->zmin);
+    n->xmax = fmaxf(v.x, n->xmax); n->ymax = fmaxf(v.y, n->ymax); n->zmax = fmaxf(v.z, n->zmax);
+}
+/* aabb.h:75-78 */
+static float box_area(const onode *n)
+{
+    float ex = n->xmax - n->xmin, ey = n->ymax - n->ymin, ez = n->zmax - n->zmin;
+    return ex * ey + ey * ez + ez * ex;
+}
+
+/* bvh.h:96-106 */
+static void update_node_bounds(ptor_scene *sc, uint32_t idx)
+{
+    onode *node = &sc->nodes[idx];
+    box_default(node);
+    for (uint32_t first = node->firstTri, i = 0; i < node->triCount; i++) {
+        const otri *t = &sc->tris[sc->indices[first + i]];
+        box_extend(node, t->v0); box_extend(node, t->v1); box_extend(node, t->v2);
+    }
+}
+static inline float centroid_axis(const otri *t, int axis)
+{
+    return axis == 0 ? t->centroid.x : (axis == 1 ? t->centroid.y : t->centroid.z);
+}
+/* bvh.h:144-176 */
+static float evaluate_sah(const ptor_scene *sc, const onode *node, int axis, float pos)
+{
+    onode lb, rb; box_default(&lb); box_default(&rb);
+    int lc = 0, rc = 0;
+    for (uint32_t i = 0; i < node->triCount; i++) {
+        const otri *t = &sc->tris[sc->indices[node->firstTri + i]];
+        if (centroid_axis(t, axis) < pos) {
+            lc++; box_extend(&lb, t->v0); box_extend(&lb, t->v1); box_extend(&lb, t->v2);
+        } else {
+            rc++; box_extend(&rb, t->v0); box_extend(&rb, t->v1); box_extend(&rb, t->v2);
+        }
+    }
+    float cost = (float)lc * box_area(&lb) + (float)rc * box_area(&rb);
+    return cost > 0 ? cost : 1e30f;
+}
+/* bvh.h:108-137 */
+static float find_best_split(const ptor_scene *sc, const onode *node, int *axis, float *splitPos)
+{
+    float best = 1e30f;
+    for (int a = 0; a < 3; a++) {
+        float bmin = a == 0 ? node->xmin : (a == 1 ? node->ymin : node->zmin);
+        float bmax = a == 0 ? node->xmax : (a == 1 ? node->ymax : node->zmax);
+        if (bmin == bmax) continue;
+        float scale = (bmax - bmin) / 4;
+        for (uint32_t i = 1; i < 4; i++) {
+            float cand = bmin + (float)i * scale;
+            float cost = evaluate_sah(sc, node, a, cand);
+            if (cost < best) { *splitPos = cand; *axis = a; best = cost; }
+        }
+    }
+    return best;
+}
+/* bvh.h:35-94 */
+static void subdivide(ptor_scene *sc, uint32_t idx)
+{
+    onode *node = &sc->nodes[idx];
+    if (node->triCount <= 5) return;
+    int axis = 0; float splitPos = 0.0f;
+    float splitCost = find_best_split(sc, node, &axis, &splitPos);
+    float nosplit = (float)node->triCount * box_area(node);       /* :139-142 */
+    if (splitCost >= nosplit) return;
+    int i = (int)node->firstTri;
+    int j = i + (int)node->triCount - 1;
+    while (i <= j) {
+        float pos = centroid_axis(&sc->tris[sc->indices[i]], axis);
+        if (pos < splitPos) i++;
+        else { int tmp = sc->indices[i]; sc->indices[i] = sc->indices[j]; sc->indices[j] = tmp; j--; }
+    }
+    int leftCount = i - (int)node->firstTri;
+    if (leftCount == 0 || leftCount == (int)node->triCount) return;
+    uint32_t l = sc->nodesUsed++, r = sc->nodesUsed++;
+    sc->nodes[l].firstTri = node->firstTri;  sc->nodes[l].triCount = (uint32_t)leftCount;
+    sc->nodes[r].firstTri = (uint32_t)i;     sc->nodes[r].triCount = node->triCount - (uint32_t)leftCount;
+    sc->nodes[l].left = sc->nodes[l].right = 0;   /* device `new` leaves these unset; never read for leaves */
+    sc->nodes[r].left = sc->nodes[r].right = 0;
+    node->left = l; node->right = r; node->triCount = 0;
+    update_node_bounds(sc, l);
+    update_node_bounds(sc, r);
+    subdivide(sc, l);
+    subdivide(sc, r);
+}
+
+/* ---------------------------------------------------------------- scene creation ---- */
+/* DevicePathTracer.h:241-340 (loadTextures, loadMaterials incl. the texture-pointer
+ * inheritance quirk :269-279, loadTrianglesWithTextures incl. the light rule :304-307)
+ * + triangle.h:17-29 + bvh.h:20-33.                                                      */
+int ptor_scene_create(const ptor_triangle *tris, int ntris,
+                      const ptor_material *mats, int nmats,
+                      const ptor_texture *texs, int ntexs,
+                      ptor_scene **out)
+{
+    if (ntris <= 0 || nmats <= 0) return 1;
+    ptor_scene *sc = (ptor_scene *)calloc(1, sizeof(*sc));
+    sc->ntexs = ntexs;
+    sc->texs = (otex *)calloc((size_t)(ntexs > 0 ? ntexs : 1), sizeof(otex));
+    for (int i = 0; i < ntexs; i++) {
+        size_t n = (size_t)texs[i].width * (size_t)texs[i].height * 3;
+        sc->texs[i].w = texs[i].width; sc->texs[i].h = texs[i].height;
+        sc->texs[i].data = (float *)malloc(n * sizeof(float) + 4);
+        memcpy(sc->texs[i].data, texs[i].data, n * sizeof(float));
+    }
+    sc->nmats = nmats;
+    sc->mats = (omat *)calloc((size_t)nmats, sizeof(omat));
+    int baseTex = -1, emisTex = -1;                  /* :269-270: declared outside the loop */
+    for (int i = 0; i < nmats; i++) {
+        if (mats[i].baseColorTextureIdx >= 0) baseTex = mats[i].baseColorTextureIdx;
+        if (mats[i].emissiveTextureIdx >= 0)  emisTex = mats[i].emissiveTextureIdx;
+        if (baseTex >= ntexs || emisTex >= ntexs) return 2;
+        sc->mats[i].baseColor = mk3(mats[i].baseColor[0], mats[i].baseColor[1], mats[i].baseColor[2]);
+        sc->mats[i].emissive  = mk3(mats[i].emissive[0], mats[i].emissive[1], mats[i].emissive[2]);
+        sc->mats[i].baseTex = baseTex; sc->mats[i].emisTex = emisTex;
+    }
+    sc->ntris = ntris;
+    sc->tris = (otri *)calloc((size_t)ntris, sizeof(otri));
+    sc->lights = (int *)calloc((size_t)ntris, sizeof(int));
+    for (int i = 0; i < ntris; i++) {
+        const ptor_triangle *h = &tris[i];
+        otri *t = &sc->tris[i];
+        if (h->materialIdx < 0 || h->materialIdx >= nmats) return 3;
+        t->v0 = mk3(h->v0.px, h->v0.py, h->v0.pz);
+        t->v1 = mk3(h->v1.px, h->v1.py, h->v1.pz);
+        t->v2 = mk3(h->v2.px, h->v2.py, h->v2.pz);
+        t->uv0[0] = h->v0.u; t->uv0[1] = h->v0.v;
+        t->uv1[0] = h->v1.u; t->uv1[1] = h->v1.v;
+        t->uv2[0] = h->v2.u; t->uv2[1] = h->v2.v;
+        t->mat = h->materialIdx;
+        t->centroid = scale3(add3(add3(t->v0, t->v1), t->v2), 0.3333f);              /* :27 */
+        t->area = length3(cross3(sub3(t->v1, t->v0), sub3(t->v2, t->v0))) * 0.5f;    /* :28 */
+        const float *e = mats[h->materialIdx].emissive;
+        if ((double)e[0] > 0.0001 || (double)e[1] > 0.0001 || (double)e[2] > 0.0001) /* :305 */
+            sc->lights[sc->nlights++] = i;
+    }
+    /* bvh.h:20-33 */
+    sc->indices = (int *)malloc(sizeof(int) * (size_t)(2 * ntris - 1));
+    sc->nodes = (onode *)calloc((size_t)(2 * ntris - 1), sizeof(onode));
+    for (int i = 0; i < ntris; i++) sc->indices[i] = i;
+    sc->nodesUsed = 1;
+    sc->nodes[0].left = sc->nodes[0].right = 0;
+    sc->nodes[0].firstTri = 0; sc->nodes[0].triCount = (uint32_t)ntris;
+    update_node_bounds(sc, 0);
+    subdivide(sc, 0);
+    *out = sc;
+    return 0;
+}
+
+void ptor_scene_destroy(ptor_scene *sc)
+{
+    if (!sc) return;
+    for (int i = 0; i < sc->ntexs; i++) free(sc->texs[i].data);
+    free(sc->texs); free(sc->mats); free(sc->tris); free(sc->lights);
+    free(sc->nodes); free(sc->indices); free(sc);
+}
+
+/* Introspection for known-answer tests. Node record = 6 floats + 4 u32 = 40 B. */
+uint32_t ptor_scene_node_count(const ptor_scene *sc) { return sc->nodesUsed; }
+int ptor_scene_light_count(const ptor_scene *sc) { return sc->nlights; }
+void ptor_scene_copy_nodes(const ptor_scene *sc, float *bounds6, uint32_t *links4)
+{
+    for (uint32_t i = 0; i < sc->nodesUsed; i++) {
+        const onode *n = &sc->nodes[i];
+        bounds6[6*i+0] = n->xmin; bounds6[6*i+1] = n->xmax; bounds6[6*i+2] = n->ymin;
+        bounds6[6*i+3] = n->ymax; bounds6[6*i+4] = n->zmin; bounds6[6*i+5] = n->zmax;
+        links4[4*i+0] = n->left; links4[4*i+1] = n->right;
+        links4[4*i+2] = n->firstTri; links4[4*i+3] = n->triCount;
+    }
+}
+void ptor_scene_copy_indices(const ptor_scene *sc, int *out)
+{
+    memcpy(out, sc->indices, sizeof(int) * (size_t)sc->ntris);
+}
+void ptor_scene_copy_lights(const ptor_scene *sc, int *out)
+{
+    memcpy(out, sc->lights, sizeof(int) * (size_t)sc->nlights);
+}
+
+/* --------------------------------------------------------------------- tracing ---- */
+typedef struct { f3 o, d; } oray;                       /* ray.h:3-22 */
+typedef struct {                                        /* hitable.h:8-14 hit_record */
+    float t; f3 p; f3 normal; int mat; float tu, tv;
+} orec;
+
+typedef struct {
+    const ptor_scene *sc;
+    ptor_rng rng;
+    ptor_counters *cnt;
+} octx;
+
+static inline float U(octx *c) { c->cnt->rng_draws++; return ptor_uniform_from(ptor_xorwow_next(&c->rng)); }
+
+/* aabb.h:38-66.  ray_t and rec are ignored by the reference. */
+static int box_hit(const onode *b, const oray *r)
+{
+    float ix = 1.0f / r->d.x, iy = 1.0f / r->d.y, iz = 1.0f / r->d.z;
+    float t1 = (b->xmin - r->o.x) * ix, t2 = (b->xmax - r->o.x) * ix;
+    float t3 = (b->ymin - r->o.y) * iy, t4 = (b->ymax - r->o.y) * iy;
+    float t5 = (b->zmin - r->o.z) * iz, t6 = (b->zmax - r->o.z) * iz;
+    float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    if (tmax < 0) return 0;
+    if (tmin > tmax) return 0;
+    return 1;
+}
+
+/* triangle.h:63-113 Moller-Trumbore. */
+static int tri_hit(const otri *tr, const oray *r, float tmin, float tmax, orec *rec)
+{
+    f3 e1 = sub3(tr->v1, tr->v0);
+    f3 e2 = sub3(tr->v2, tr->v0);
+    f3 pvec = cross3(r->d, e2);
+    float det = dot3(e1, pvec);
+    if ((double)det < 1e-8 && (double)det > -1e-8) return 0;                 /* :78 */
+    float inv_det = (float)(1.0 / (double)det);                              /* :84 */
+    f3 tvec = sub3(r->o, tr->v0);
+    float u = dot3(tvec, pvec) * inv_det;
+    if (u < 0 || u > 1) return 0;
+    f3 qvec = cross3(tvec, e1);
+    float v = dot3(r->d, qvec) * inv_det;
+    if (v < 0 || u + v > 1) return 0;
+    float t = dot3(e2, qvec) * inv_det;
+    if (t < tmax && t > tmin) {
+        rec->t = t;
+        rec->p = add3(r->o, scale3(r->d, t));                                /* ray.h:18 A + t*B */
+        rec->normal = normalize3(cross3(e1, e2));
+        rec->mat = tr->mat;
+        rec->tu = (1 - u - v) * tr->uv0[0] + u * tr->uv1[0] + v * tr->uv2[0];
+        rec->tv = (1 - u - v) * tr->uv0[1] + u * tr->uv1[1] + v * tr->uv2[1];
+        return 1;
+    }
+    return 0;
+}
+
+/* bvh.h:178-246 */
+static int bvh_hit(octx *c, const oray *r, float tmin, float tmax_in, orec *rec, int *err)
+{
+    const ptor_scene *sc = c->sc;
+    const onode *stack[64];
+    int sp = 0;
+    stack[sp++] = NULL;
+    int found = 0;
+    float tmax = tmax_in;
+    const onode *node = &sc->nodes[0];
+    do {
+        const onode *cl = &sc->nodes[node->left];
+        const onode *cr = &sc->nodes[node->right];
+        int ol = box_hit(cl, r);
+        int orr = box_hit(cr, r);
+        c->cnt->box_tests += 2;
+        if (ol && cl->triCount != 0) {
+            for (uint32_t first = cl->firstTri, i = 0; i < cl->triCount; i++) {
+                c->cnt->tri_tests++;
+                if (tri_hit(&sc->tris[sc->indices[first + i]], r, tmin, tmax, rec)) { tmax = rec->t; found = 1; }
+            }
+        }
+        if (orr && cr->triCount != 0) {
+            for (uint32_t first = cr->firstTri, i = 0; i < cr->triCount; i++) {
+                c->cnt->tri_tests++;
+                if (tri_hit(&sc->tris[sc->indices[first + i]], r, tmin, tmax, rec)) { tmax = rec->t; found = 1; }
+            }
+        }
+        int tl = ol && cl->triCount == 0;
+        int trr = orr && cr->triCount == 0;
+        if (!tl && !trr) {
+            node = stack[--sp];
+        } else if (tl && trr) {
+            /* :228-236: distR < distL compares two copies of the same rec.t -> always left first */
+            node = cl;
+            if (sp >= 64) { *err = 1; return 0; }      /* reference: stack overflow = UB */
+            stack[sp++] = cr;
+            if ((uint64_t)sp > c->cnt->max_stack) c->cnt->max_stack = (uint64_t)sp;
+        } else {
+            node = tl ? cl : cr;
+        }
+    } while (node != NULL);
+    return found;
+}
+
+/* Texture.h:30-69 BaseColorTexture::value + pixel_data.  Row `height_` (one past the end,
+ * reached when j == 0) is undefined behaviour in the reference; this restatement clamps
+ * the row to height_-1 (documented choice).                                   */
+static f3 tex_value(const otex *t, float u, float v)
+{
+    if (t->h <= 0) return mk3((float)242 / 255, (float)45 / 255, (float)27 / 255);
+    u = fmodf(u, 1.0f); v = fmodf(v, 1.0f);
+    int i = (int)(u * (float)t->w);
+    int j = (int)(v * (float)t->h);
+    int x = i < 0 ? 0 : (i < t->w ? i : t->w - 1);
+    int y = j < 0 ? 0 : (j < t->h ? j : t->h - 1);
+    y = t->h - y;
+    if (y > t->h - 1) y = t->h - 1;
+    const float *px = &t->data[3 * ((size_t)y * (size_t)t->w + (size_t)x)];
+    double cs = 1.0 / 255.0;
+    return mk3((float)(cs * (double)px[0]), (float)(cs * (double)px[1]), (float)(cs * (double)px[2]));
+}
+
+/* onb.h:8-13 */
+typedef struct { f3 a0, a1, a2; } oonb;
+static oonb onb_make(f3 n)
+{
+    oonb b;
+    b.a2 = normalize3(n);
+    f3 a = fabsf(b.a2.x) > 0.9f ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
+    b.a1 = normalize3(cross3(b.a2, a));
+    b.a0 = cross3(b.a2, b.a1);
+    return b;
+}
+/* onb.h:20-22 */
+static f3 onb_local(const oonb *b, f3 v)
+{
+    return add3(add3(scale3(b->a0, v.x), scale3(b->a1, v.y)), scale3(b->a2, v.z));
+}
+/* helper_math.h:1519-1527 (note the reference's extra factor 2 on x and y). */
+static f3 random_cosine_direction(octx *c)
+{
+    float r1 = U(c), r2 = U(c);
+    float z = sqrtf(1 - r2);
+    float phi = (float)(2 * M_PI * (double)r1);
+    float s, co; ptor_sincosf(phi, &s, &co);
+    float x = co * 2 * sqrtf(r2);
+    float y = s * 2 * sqrtf(r2);
+    return mk3(x, y, z);
+}
+
+/* triangle.h:32-40 */
+static float tri_pdf_value(octx *c, const otri *tr, f3 o, f3 v)
+{
+    orec rec; memset(&rec, 0, sizeof rec);
+    oray r = {o, v};
+    c->cnt->light_tests++;
+    if (!tri_hit(tr, &r, 0.001f, FLT_MAX, &rec)) return 0;
+    float distance_squared = rec.t * rec.t * dot3(v, v);
+    float cosine = fabsf(dot3(v, rec.normal) / length3(v));
+    return distance_squared / (cosine * tr->area);
+}
+/* triangle.h:41-47 */
+static f3 tri_random(octx *c, const otri *tr, f3 o)
+{
+    float r1 = U(c), r2 = U(c);
+    float sq = sqrtf(r1);
+    f3 p = add3(add3(scale3(tr->v0, 1 - sq), scale3(tr->v1, sq * (1 - r2))), scale3(tr->v2, sq * r2));
+    return sub3(p, o);
+}
+
+/* camera.h:49-83 ray_color, with material.h:52-91 (scatter / emitted / scattering_pdf),
+ * pdf.h:13-72 (cosine_pdf, hitable_list_pdf, mixture_pdf) and hitable_list.h:16-26
+ * flattened in call order.  Returns the radiance of one path.                            */
+static f3 ray_color(octx *c, oray ray, unsigned depth, int *err)
+{
+    const ptor_scene *sc = c->sc;
+    f3 atten = mk3(1.0f, 1.0f, 1.0f);
+    for (unsigned i = 0; i < depth; i++) {
+        orec rec; memset(&rec, 0, sizeof rec);
+        c->cnt->segments++;
+        if (bvh_hit(c, &ray, 0.001f, FLT_MAX, &rec, err)) {
+            const omat *m = &sc->mats[rec.mat];
+            /* material.h:80-86 emitted */
+            f3 emitted;
+            if (m->emisTex >= 0) emitted = scale3(mul3(tex_value(&sc->texs[m->emisTex], rec.tu, rec.tv), m->emissive), 50);
+            else                 emitted = scale3(m->emissive, 50);
+            if ((double)emitted.x > 0.0001 || (double)emitted.y > 0.0001 || (double)emitted.z > 0.0001) {
+                return mul3(atten, emitted);                                  /* camera.h:72-74 */
+            }
+            /* material.h:67-77: onb + random_cosine_direction whose result is overwritten
+             * at camera.h:65 -- only its two RNG draws are observable.                   */
+            (void)U(c); (void)U(c);
+            f3 albedo = m->baseColor;
+            if (m->baseTex >= 0) albedo = mul3(albedo, tex_value(&sc->texs[m->baseTex], rec.tu, rec.tv));
+            /* camera.h:62-66 */
+            oonb uvw = onb_make(rec.normal);                                   /* cosine_pdf ctor */
+            f3 dir;
+            if (U(c) < 0.5f) {                                                 /* pdf.h:66-72 */
+                /* hitable_list.h:23-26 */
+                float uu = U(c);
+                int idx = (int)truncf((float)((double)uu * ((sc->nlights - 1) + 0.999999)));
+                dir = tri_random(c, &sc->tris[sc->lights[idx]], rec.p);
+            } else {
+                dir = onb_local(&uvw, random_cosine_direction(c));             /* pdf.h:24-26 */
+            }
+            /* pdf.h:63-65 mixture value */
+            float weight = 1.0f / (float)sc->nlights;                          /* hitable_list.h:17 */
+            float lsum = 0.0f;
+            for (int k = 0; k < sc->nlights; k++)
+                lsum += weight * tri_pdf_value(c, &sc->tris[sc->lights[k]], rec.p, dir);
+            float cosv = dot3(normalize3(dir), uvw.a2);                        /* pdf.h:19-22 */
+            float cpdf = (cosv <= 0) ? 0 : (float)((double)cosv / M_PI);
+            float pdf_value = 0.5f * lsum + 0.5f * cpdf;
+            /* material.h:88-91 */
+            float cos2 = dot3(rec.normal, normalize3(dir));
+            float spdf = cos2 < 0 ? 0 : (float)((double)cos2 / M_PI);
+            atten = mul3(atten, div3s(scale3(albedo, spdf), pdf_value));       /* camera.h:69 */
+            ray.o = rec.p; ray.d = dir;
+        } else {
+            return mul3(mk3(0.0f, 0.0f, 0.0f), atten);                         /* camera.h:78-79 */
+        }
+    }
+    return mk3(0.0f, 0.0f, 0.0f);                                              /* camera.h:82 */
+}
+
+/* float -> int as CUDA cvt.rzi.s32.f32 (and gfx950 v_cvt_i32_f32) define it:
+ * truncate, saturate, NaN -> 0 (x86 cvttss2si would give INT_MIN). */
+static int f2i_rz_sat(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return INT32_MAX;
+    if (f <= -2147483648.0f) return INT32_MIN;
+    return (int)f;
+}
+
+/* camera.h:21-36 recalculate_camera_params; uniform per frame. */
+typedef struct { f3 origin, llc, horizontal, vertical; } ocam;
+static ocam camera_setup(const ptor_camera *cfg)
+{
+    ocam cam;
+    f3 from = mk3(cfg->lookFrom[0], cfg->lookFrom[1], cfg->lookFrom[2]);
+    f3 front = mk3(cfg->front[0], cfg->front[1], cfg->front[2]);
+    f3 lookAt = add3(from, front);
+    float theta_v = (float)((double)cfg->vfov * M_PI / 180);
+    float half_height = ptor_tanf(theta_v / 2);
+    float theta_h = (float)((double)cfg->hfov * M_PI / 180);
+    float half_width = ptor_tanf(theta_h / 2);
+    f3 vup = mk3(0.0f, 1.0f, 0.0f);                                           /* camera.h:111 */
+    f3 w = normalize3(sub3(from, lookAt));
+    f3 u = normalize3(cross3(vup, w));
+    f3 v = cross3(w, u);
+    cam.origin = from;
+    cam.llc = sub3(sub3(sub3(from, scale3(u, half_width)), scale3(v, half_height)), w);
+    cam.horizontal = scale3(u, 2 * half_width);
+    cam.vertical = scale3(v, 2 * half_height);
+    return cam;
+}
+
+/* DevicePathTracer.h:73-120 `render`, one call = one RenderTask rectangle.
+ * rgb: 3*W*H bytes, yuv: W*H + 2*(W*H/4) bytes (Framebuffer.h:27-35).
+ * Returns 0, or 1 if the 64-entry traversal stack would overflow (reference: UB).        */
+int ptor_render(const ptor_scene *sc, const ptor_camera *cfg, int W, int H,
+                int spp, unsigned depth, const ptor_task *task,
+                uint8_t *rgb, uint8_t *yuv, ptor_counters *cnt)
+{
+    ptor_counters local; memset(&local, 0, sizeof local);
+    if (sc->nlights <= 0) return 2;       /* reference: list[idx] of an empty list = UB */
+    ocam cam = camera_setup(cfg);
+    int err = 0;
+    for (int j = 0; j < task->height; j++) {
+        for (int i = 0; i < task->width; i++) {
+            int x = task->offset_x + i;
+            int y = task->offset_y + j;
+            if (x >= W || y >= H || x < 0 || y < 0) continue;
+            int pixel_index = (H - y - 1) * W + x;
+            octx c; c.sc = sc; c.cnt = &local;
+            ptor_xorwow_init(&c.rng, (uint64_t)(1984 + pixel_index));         /* :54, :80 */
+            f3 col = mk3(0, 0, 0);
+            for (int s = 0; s < spp; s++) {
+                float u = ((float)x + U(&c)) / (float)(unsigned)W;
+                float v = ((float)y + U(&c)) / (float)(unsigned)H;
+                oray r;                                                       /* camera.h:95-97 */
+                r.o = cam.origin;
+                r.d = sub3(add3(add3(cam.llc, scale3(cam.horizontal, u)), scale3(cam.vertical, v)), cam.origin);
+                local.paths++;
+                col = add3(col, ray_color(&c, r, depth, &err));
+                if (err) return 1;
+            }
+            if (col.x != col.x || col.y != col.y || col.z != col.z) local.nan_pixels++;
+            /* :98-101 */
+            f3 q = div3s(scale3(col, 255.99f), (float)spp);
+            int cr = f2i_rz_sat(q.x * 1.0f), cg = f2i_rz_sat(q.y * 1.0f), cb = f2i_rz_sat(q.z * 1.0f);
+            cr = cr < 255 ? cr : 255; cg = cg < 255 ? cg : 255; cb = cb < 255 ? cb : 255;
+            rgb[3 * pixel_index] = (uint8_t)cr;
+            rgb[3 * pixel_index + 1] = (uint8_t)cg;
+            rgb[3 * pixel_index + 2] = (uint8_t)cb;
+            /* :106-119 */
+            yuv[pixel_index] = (uint8_t)(((66 * cr + 129 * cg + 25 * cb + 128) >> 8) + 16);
+            int blockRow = pixel_index / W, blockCol = pixel_index % W;
+            if (blockRow % 2 == 0 && blockCol % 2 == 0) {
+                int total = W * H, uvSize = total / 4;
+                int uvIndex = (blockRow / 2) * (W / 2) + (blockCol / 2);
+                if (uvIndex >= uvSize) continue;   /* odd W/H: the reference writes past its planes */
+                yuv[total + uvIndex] = (uint8_t)(((-38 * cr - 74 * cg + 112 * cb + 128) >> 8) + 128);
+                yuv[total + uvSize + uvIndex] = (uint8_t)(((112 * cr - 94 * cg - 18 * cb + 128) >> 8) + 128);
+            }
+        }
+    }
+    if (cnt) {
+        cnt->paths += local.paths; cnt->segments += local.segments; cnt->box_tests += local.box_tests;
+        cnt->tri_tests += local.tri_tests; cnt->light_tests += local.light_tests;
+        cnt->rng_draws += local.rng_draws; cnt->nan_pixels += local.nan_pixels;
+        if (local.max_stack > cnt->max_stack) cnt->max_stack = local.max_stack;
+    }
+    return 0;
+}
+
+/* Single-ray known-answer helpers (tests only). */
+int ptor_kat_box_hit(const float b6[6], const float o[3], const float d[3])
+{
+    onode n; n.xmin = b6[0]; n.xmax = b6[1]; n.ymin = b6[2]; n.ymax = b6[3]; n.zmin = b6[4]; n.zmax = b6[5];
+    oray r = {mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2])};
+    return box_hit(&n, &r);
+}
+int ptor_kat_tri_hit(const float v[9], const float o[3], const float d[3], float tmin, float tmax,
+                     float out_t_u_v[3])
+{
+    otri t; memset(&t, 0, sizeof t);
+    t.v0 = mk3(v[0], v[1], v[2]); t.v1 = mk3(v[3], v[4], v[5]); t.v2 = mk3(v[6], v[7], v[8]);
+    t.uv1[0] = 1.0f; t.uv2[1] = 1.0f;          /* texCoord = (u, v) barycentrics */
+    oray r = {mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2])};
+    orec rec; memset(&rec, 0, sizeof rec);
+    int h = tri_hit(&t, &r, tmin, tmax, &rec);
+    out_t_u_v[0] = rec.t; out_t_u_v[1] = rec.tu; out_t_u_v[2] = rec.tv;
+    return h;
+}
+/* Closest hit of one ray through the reference-order traversal (tests only). */
+int ptor_kat_closest_hit(const ptor_scene *sc, const float o[3], const float d[3],
+                         float *t_out, int *mat_out)
+{
+    ptor_counters cn; memset(&cn, 0, sizeof cn);
+    octx c; c.sc = sc; c.cnt = &cn; ptor_xorwow_init(&c.rng, 0);
+    oray r = {mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2])};
+    orec rec; memset(&rec, 0, sizeof rec);
+    int err = 0;
+    int h = bvh_hit(&c, &r, 0.001f, FLT_MAX, &rec, &err);
+    *t_out = rec.t; *mat_out = rec.mat;
+    return err ? -1 : h;
+}
