@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json): ray-segments/s and
+ms/frame on Cornell box 1920x1080, 256 spp, 8 bounces, on 1..N MI355X.
+
+A "step" is one frame = RenderManager.renderFrame(): every rank renders its row bands of the
+frame (scene replicated per GPU) and the bands are gathered to rank 0 (the path's one
+exchange step).  Inputs (scene, BVH) are resident in HBM before the timed region.  The
+image is deterministic (per-pixel seeds), so every frame does identical work.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c4]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md "Measurement").
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+CONFIGS = {
+    # name: (scene, W, H, spp, depth, description)
+    "c1": ("box", 400, 400, 16, 4, "cornell_box.glb 400x400 16spp 4bounce"),
+    "c2": ("box", 1920, 1080, 256, 8, "cornell_box.glb 1920x1080 256spp 8bounce"),
+    "c3": ("duck", 1920, 1080, 256, 8, "cornell_duck.glb 1920x1080 256spp 8bounce"),
+    "c4": ("terrain", 1920, 1080, 64, 8, "8M-triangle synthetic terrain 1920x1080 64spp 8bounce"),
+}
+BOX_CAMERA = ((-255.5, 252.5, 700.0), (0.0, 0.0, -1.0))      # SURVEY.md 8d benchmark convention
+DUCK_CAMERA = ((0.0, 0.0, 0.5), (0.0, 0.0, -0.5))            # main.cu:40
+TERRAIN_CAMERA = ((0.0, 220.0, 620.0), (0.0, -0.35, -1.0))
+
+
+def algorithmic_bytes(cnt, pixels):
+    """B = 32*n_box + 40*n_tri + 40*n_light + 64*segments + 4.5 B/pixel."""
+    return (32 * cnt["box_tests"] + 40 * cnt["tri_tests"] + 40 * cnt["light_tests"] + 64 * cnt["segments"]
+            + 4.5 * pixels)
+
+
+def load_scene(pt, kind):
+    if kind == "box":
+        sc = pt.SceneLoader().load(os.path.join(ROOT, "models", "cornell_box.glb")).applyCornellConvention()
+        return sc, BOX_CAMERA
+    if kind == "duck":
+        return pt.SceneLoader().load(os.path.join(ROOT, "models", "cornell_duck.glb")), DUCK_CAMERA
+    return pt.make_terrain_scene(2048), TERRAIN_CAMERA
+
+
+def cpu_baseline(scene, camera, W, H, spp, depth, budget_rows):
+    """The oracle (CPU restatement of the reference integrator) timed on this host's cores on
+    a bounded sample of the SAME workload: a centred full-width strip of the frame."""
+    from oracle import binding as ob
+    cores = min(os.cpu_count() or 1, 16)
+    osc = ob.OracleScene(scene.triangles, scene.materials, scene.textures)
+    rows = max(cores, min(H, budget_rows))
+    oy = (H - rows) // 2
+    cam = (camera[0], camera[1], 45.0, 45.0)
+    t0 = time.perf_counter()
+    _, _, cnt = osc.render(cam, W, H, spp, depth, task=(W, rows, 0, oy), threads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": cnt["segments"] / dt, "unit": "ray-segments/s", "cores": cores, "kind": "port",
+        "sample": "task %dx%d at offset_y=%d of the %dx%d frame (%.1f%% of pixels), %d spp, %d bounces, %.1f s"
+                  % (W, rows, oy, W, H, 100.0 * rows / H, spp, depth, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--band-rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=48)
+    ap.add_argument("--ppm", default=None, help="write the gathered frame of the last step here")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    pt = importlib.import_module("multi-gpu-path-tracer_amd")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path is mandatory, there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    kind, W, H, spp, depth, desc = CONFIGS[args.config]
+    scene, camera = load_scene(pt, kind)
+    cfg = pt.RendererConfig(samplesPerPixel=spp, recursionDepth=depth, gpuNumber=world,
+                            resolution=pt.Resolution(W, H), showTasks=False)
+    cam = pt.CameraConfig(camera[0], camera[1])
+    mgr = pt.RenderManager(cfg, scene, cam, device_idx=local_rank, band_rows=args.band_rows)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        mgr.renderFrame()
+    sync_all()
+    mgr.tracer.resetCounters()
+    mgr.tracer.resetKernelTime()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mgr.renderFrame()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    # max over ranks of the timed region; sum over ranks of the exact work counters
+    cnt = mgr.tracer.readCounters()
+    kernel_ms, launches = mgr.tracer.kernelTime()
+    keys = ["paths", "segments", "box_tests", "tri_tests", "light_tests"]
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([float(cnt[k]) for k in keys], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total = {k: int(v) for k, v in zip(keys, tot.tolist())}
+    else:
+        total = cnt
+
+    if rank == 0:
+        if args.ppm:
+            pt.write_ppm(args.ppm, mgr.getCurrentFrame())
+        seg_per_s = total["segments"] / elapsed
+        # roofline of the dominant (only) kernel, from rank 0's own launches
+        my_pixels = sum(t.width * t.height for t in mgr.renderTasks_) * args.steps
+        bytes_rank0 = algorithmic_bytes(cnt, my_pixels)
+        achieved = bytes_rank0 / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "ray-segments/s", "value": seg_per_s, "unit": "ray-segments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "scene": kind, "width": W, "height": H, "spp": spp, "bounces": depth,
+                       "parallelism": "row-bands x%d (band_rows=%d), scene replicated, gather to rank 0"
+                                      % (world, args.band_rows)},
+            "segments_per_frame": total["segments"] // args.steps,
+            "segments_per_path": total["segments"] / max(total["paths"], 1),
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "pt::dev::render_kernel", "kernel_ms_avg": kernel_ms / max(launches, 1),
+                "launches": launches,
+                "algorithmic_bytes_per_segment": bytes_rank0 / max(cnt["segments"], 1),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, camera, W, H, spp, depth, args.cpu_rows)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

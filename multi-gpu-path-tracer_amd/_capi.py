@@ -119,6 +119,13 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). The HIP path is mandatory; there is no fallback." % LIB_PATH)
+        # torch bundles its own HIP/HSA runtime (same soname, libamdhip64.so.7).  Two HIP
+        # runtimes in one process cannot both own the GPU, so make sure torch's copy is the
+        # one already loaded when libptamd.so's DT_NEEDED entry is resolved.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in _PROTOS.items():
             fn = getattr(handle, name)      # AttributeError = header/library mismatch

@@ -1,0 +1,159 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle.
+
+Bar: bit-exact.  The render path's floating-point contract makes every
+operation a single IEEE op or an explicit fmaf, so RGB/YUV bytes and the work counters must
+be IDENTICAL to the oracle's, not merely close.
+"""
+import numpy as np
+import pytest
+
+from conftest import BOX_CAMERA, DUCK_CAMERA
+
+pytestmark = pytest.mark.gpu
+
+
+def _render_gpu(pt, scene, camera, W, H, spp, depth, tasks=None, device=0):
+    cam = pt.CameraConfig(camera[0], camera[1], camera[2], camera[3])
+    fb = pt.Framebuffer(pt.Resolution(W, H), device="cuda:%d" % device)
+    tracer = pt.DevicePathTracer(device, spp, depth, (8, 8), scene, fb, cam)
+    tracer.resetCounters()
+    for t in (tasks or [pt.RenderTask(W, H, 0, 0)]):
+        tracer.renderTaskAsync(t)
+    tracer.waitForRenderTask()
+    rgb, yuv, cnt = fb.rgb_host().copy(), fb.yuv_host().copy(), tracer.readCounters()
+    tracer.close()
+    return rgb, yuv, cnt
+
+
+def _assert_same(gpu, ref):
+    g_rgb, g_yuv, g_cnt = gpu
+    r_rgb, r_yuv, r_cnt = ref
+    diff = np.argwhere(g_rgb != r_rgb)
+    assert diff.size == 0, "RGB differs at %d bytes, first %s: gpu %s ref %s" % (
+        len(diff), diff[0], g_rgb[tuple(diff[0])], r_rgb[tuple(diff[0])])
+    assert np.array_equal(g_yuv, r_yuv), "YUV differs"
+    for k in ("paths", "segments", "box_tests", "tri_tests", "light_tests"):
+        assert g_cnt[k] == r_cnt[k], (k, g_cnt[k], r_cnt[k])
+
+
+def test_device_arithmetic_is_ieee_and_matches_oracle(pt, ob, box_scene, gpu_device):
+    """sin/cos polynomial, /, sqrt, double-divide-by-pi and XORWOW: device == host, bitwise."""
+    fb = pt.Framebuffer(pt.Resolution(8, 8))
+    tr = pt.DevicePathTracer(0, 1, 1, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
+    rng = np.random.default_rng(7)
+    # sincos over the path's domain (0, 2*pi]
+    x = np.concatenate([rng.uniform(0, 2 * np.pi, 20000), [0.0, np.pi / 4, np.pi / 2, np.pi, 2 * np.pi, 6.2831855]]).astype(np.float32)
+    s, c = tr.katArith(0, x)
+    ref = np.array([ob.sincos(float(v)) for v in x], np.float32)
+    assert np.array_equal(s.view(np.uint32), ref[:, 0].view(np.uint32))
+    assert np.array_equal(c.view(np.uint32), ref[:, 1].view(np.uint32))
+    assert np.max(np.abs(s.astype(np.float64) - np.sin(x.astype(np.float64)))) < 3e-7
+    assert np.max(np.abs(c.astype(np.float64) - np.cos(x.astype(np.float64)))) < 3e-7
+    # division / sqrt: correctly rounded, incl. denormal results and huge ratios
+    a = np.concatenate([rng.standard_normal(50000) * 10.0 ** rng.integers(-30, 30, 50000), [1.0, 1.0, 0.0, 1e-40]]).astype(np.float32)
+    b = np.concatenate([rng.standard_normal(50000) * 10.0 ** rng.integers(-30, 30, 50000), [3.0, 0.0, 0.0, 1e30]]).astype(np.float32)
+    with np.errstate(all="ignore"):
+        q, _ = tr.katArith(1, a, b)
+        assert np.array_equal(q.view(np.uint32), (a / b).view(np.uint32))
+        r, _ = tr.katArith(2, np.abs(a))
+        assert np.array_equal(r.view(np.uint32), np.sqrt(np.abs(a)).view(np.uint32))
+        d, _ = tr.katArith(3, a)
+        assert np.array_equal(d.view(np.uint32), (a.astype(np.float64) / np.pi).astype(np.float32).view(np.uint32))
+    # XORWOW: uniforms #0..#7 for the seeds of pixel 0, pixel 1 and the last pixel of 1080p
+    for seed in (1984, 1985, 1984 + 1920 * 1080 - 1):
+        _, ref_u = ob.xorwow_uniforms(seed, 8)
+        seeds = np.full(8, seed, np.uint32).view(np.float32)
+        skips = np.arange(8, dtype=np.uint32).view(np.float32)
+        got, _ = tr.katArith(4, seeds, skips)
+        assert np.array_equal(got.view(np.uint32), ref_u.view(np.uint32))
+    tr.close()
+
+
+@pytest.mark.parametrize("name", ["box", "duck"])
+def test_device_bvh_equals_oracle_bvh(pt, ob, box_scene, duck_scene, box_oracle, duck_oracle, gpu_device, name):
+    scene, osc = (box_scene, box_oracle) if name == "box" else (duck_scene, duck_oracle)
+    fb = pt.Framebuffer(pt.Resolution(8, 8))
+    tr = pt.DevicePathTracer(0, 1, 1, (8, 8), scene, fb, pt.CameraConfig((0, 0, 0), (0, 0, -1)))
+    b, l, i, lights = tr.bvhCopy()
+    ob_b, ob_l, ob_i, ob_lights = osc.bvh()
+    assert np.array_equal(b.view(np.uint32), ob_b.view(np.uint32))
+    assert np.array_equal(l, ob_l) and np.array_equal(i, ob_i) and np.array_equal(lights, ob_lights)
+    tr.close()
+
+
+@pytest.mark.parametrize("name,n", [("box", 4000), ("duck", 600)])
+def test_closest_hit_matches_oracle_on_random_rays(pt, box_scene, duck_scene, box_oracle, duck_oracle, gpu_device, name, n):
+    scene, osc, cam = (box_scene, box_oracle, BOX_CAMERA) if name == "box" else (duck_scene, duck_oracle, DUCK_CAMERA)
+    fb = pt.Framebuffer(pt.Resolution(8, 8))
+    tr = pt.DevicePathTracer(0, 1, 1, (8, 8), scene, fb, pt.CameraConfig(cam[0], cam[1]))
+    rng = np.random.default_rng(3)
+    tris = scene.triangles
+    lo = np.min([tris[v]["position"].min(axis=0) for v in ("v0", "v1", "v2")], axis=0)
+    hi = np.max([tris[v]["position"].max(axis=0) for v in ("v0", "v1", "v2")], axis=0)
+    org = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    dirs = rng.standard_normal((n, 3)).astype(np.float32)
+    dirs[::7, 0] = 0.0          # axis-parallel components: 1/0 = inf in the slab test
+    dirs[::11, 1] = 0.0
+    t, face = tr.katClosestHit(org, dirs)
+    mats = tris["materialIdx"]
+    for k in range(n):
+        h, rt, rm = osc.closest_hit(org[k], dirs[k])
+        if h:
+            assert face[k] >= 0 and np.float32(rt).view(np.uint32) == t[k].view(np.uint32), (k, rt, t[k])
+            assert mats[face[k]] == rm
+        else:
+            assert face[k] == -1
+    tr.close()
+
+
+@pytest.mark.parametrize("W,H,spp,depth", [(64, 64, 4, 4), (200, 120, 8, 8), (50, 34, 3, 1)])
+def test_cornell_box_image_bit_exact(pt, box_scene, box_oracle, gpu_device, W, H, spp, depth):
+    ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, W, H, spp, depth), ref)
+
+
+def test_cornell_box_config1_400x400_16spp_4bounce(pt, box_scene, box_oracle, gpu_device):
+    """BASELINE.json configs[0]: the reference's own CPU-runnable case, at full size."""
+    ref = box_oracle.render(BOX_CAMERA, 400, 400, 16, 4, threads=8)
+    _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, 400, 400, 16, 4), ref)
+
+
+@pytest.mark.parametrize("W,H,spp,depth", [(64, 36, 2, 4), (96, 54, 3, 8)])
+def test_cornell_duck_image_bit_exact(pt, duck_scene, duck_oracle, gpu_device, W, H, spp, depth):
+    ref = duck_oracle.render(DUCK_CAMERA, W, H, spp, depth, threads=8)
+    _assert_same(_render_gpu(pt, duck_scene, DUCK_CAMERA, W, H, spp, depth), ref)
+
+
+def test_task_partition_invariance(pt, box_scene, box_oracle, gpu_device):
+    """RNG state is never written back (DevicePathTracer.h:80): the image is independent of
+    how the frame is cut into RenderTasks -- ragged rectangles included."""
+    W, H, spp, depth = 100, 76, 4, 5
+    whole = _render_gpu(pt, box_scene, BOX_CAMERA, W, H, spp, depth)
+    tasks = [pt.RenderTask(37, 30, 0, 0), pt.RenderTask(63, 30, 37, 0), pt.RenderTask(100, 1, 0, 30),
+             pt.RenderTask(100, 45, 0, 31), pt.RenderTask(0, 10, 5, 5)]          # width 0 = no-op (:195)
+    parts = _render_gpu(pt, box_scene, BOX_CAMERA, W, H, spp, depth, tasks=tasks)
+    _assert_same(parts, whole)
+    _assert_same(whole, box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8))
+
+
+def test_edge_cases(pt, box_scene, box_oracle, gpu_device):
+    # depth 0: ray_color returns black without tracing; spp 1; single-pixel-wide task
+    for (W, H, spp, depth) in [(16, 16, 2, 0), (16, 16, 1, 2), (2, 2, 5, 3)]:
+        ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth)
+        got = _render_gpu(pt, box_scene, BOX_CAMERA, W, H, spp, depth)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    # error behaviour at the boundary
+    fb = pt.Framebuffer(pt.Resolution(16, 16))
+    tr = pt.DevicePathTracer(0, 1, 1, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
+    with pytest.raises(pt.capi.PtError) as e:
+        tr.renderTaskAsync(pt.RenderTask(17, 4, 0, 0))        # leaves the framebuffer
+    assert e.value.status == 1
+    tr.close()
+    # a scene without emissive faces is undefined behaviour in the reference -> explicit error
+    tris = box_scene.triangles
+    mats = box_scene.materials.copy()
+    mats["emissiveFactor"] = 0
+    dark = pt.HostScene.from_arrays(tris, mats)
+    with pytest.raises(pt.capi.PtError) as e:
+        pt.DevicePathTracer(0, 1, 1, (8, 8), dark, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
+    assert e.value.status == 3
