@@ -1,0 +1,195 @@
+"""CPU tests of the product's host side (no GPU compute): scene I/O, BVH build, task
+generators, band packing, error behaviour, and that the C-ABI library exports every symbol
+include/pt_amd.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_capi_exports_every_declared_symbol(pt):
+    hdr = open(os.path.join(ROOT, "include", "pt_amd.h")).read()
+    names = re.findall(r"PT_API\s+[\w\s\*]+?\b(pt_\w+)\s*\(", hdr)
+    assert len(names) >= 40
+    handle = C.CDLL(pt.capi.LIB_PATH)
+    missing = [n for n in names if not hasattr(handle, n)]
+    assert not missing, missing
+    # and the Python binding covers the same set
+    assert sorted(set(names)) == sorted(pt.capi._PROTOS.keys())
+    assert pt.capi.lib().pt_version().decode().startswith("ptamd")
+
+
+def test_capi_signatures_carry_no_torch_or_hip_types():
+    hdr = open(os.path.join(ROOT, "include", "pt_amd.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    for banned in ("hipStream_t", "torch", "at::", "std::", "float3", "dim3", "#include <hip"):
+        assert banned not in code, banned
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "multi-gpu-path-tracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".c", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                for line in text.splitlines():
+                    if re.search(r'(#include|import|from|dlopen|CDLL).*\boracle\b', line):
+                        pytest.fail("product file %s references the oracle: %s" % (f, line))
+                    assert "libpt_oracle" not in line and "ptor_" not in line, (f, line)
+
+
+@pytest.mark.parametrize("name", ["box", "duck"])
+def test_glb_loader_reproduces_hostscene_dump(pt, box_scene, duck_scene, name):
+    sc = box_scene if name == "box" else duck_scene
+    g = np.load(os.path.join(GOLD, "hostscene_%s.npz" % name))
+    assert sc.triangles.tobytes() == g["triangles"].tobytes()
+    assert sc.materials.tobytes() == g["materials"].tobytes()
+
+
+def test_glb_loader_semantics(pt, box_scene, duck_scene):
+    # triangles regrouped by material index ascending
+    for sc in (box_scene, duck_scene):
+        m = sc.triangles["materialIdx"]
+        assert np.all(np.diff(m) >= 0)
+    # box: mat0 6, mat1 2, mat2 2, mat3 24, mat4 2 triangles
+    assert np.bincount(box_scene.triangles["materialIdx"]).tolist() == [6, 2, 2, 24, 2]
+    assert len(duck_scene.triangles) == 4224 and np.bincount(duck_scene.triangles["materialIdx"])[4] == 4212
+    # benchmark convention: the diffuse_light material became emissive (1,1,1); up = +Y
+    assert box_scene.material_names[4] == "diffuse_light"
+    assert box_scene.materials["emissiveFactor"][4].tolist() == [1, 1, 1]
+    pos = np.concatenate([box_scene.triangles[v]["position"] for v in ("v0", "v1", "v2")])
+    assert pos[:, 1].min() > -1 and pos[:, 1].max() > 500            # floor at y ~ 0, ceiling ~ 505
+    # duck: emissive (1,1,1) from the file, strength extension ignored; 512x512 palette PNG texture
+    assert duck_scene.materials["emissiveFactor"][2].tolist() == [1, 1, 1]
+    (tex,) = duck_scene.textures
+    assert tex.shape == (512, 512, 3) and tex.min() >= 0 and tex.max() <= 255 and len(np.unique(tex.reshape(-1, 3), axis=0)) <= 54
+    uv = duck_scene.triangles["v0"]["texCoords"][duck_scene.triangles["materialIdx"] == 4]
+    assert uv.min() >= 0 and uv.max() <= 1 and uv.std() > 0.05
+    assert np.all(duck_scene.triangles["v0"]["texCoords"][:12] == 0)  # meshes without TEXCOORD_0 (HostScene.cpp:214)
+
+
+def test_loader_error_behaviour(pt, tmp_path):
+    with pytest.raises(RuntimeError):
+        pt.SceneLoader().load(str(tmp_path / "missing.glb"))
+    with pytest.raises(RuntimeError):
+        pt.SceneLoader().load("model.fbx")                            # HostScene.cpp:134 unsupported type
+    bad = tmp_path / "bad.glb"
+    bad.write_bytes(b"glTF" + b"\x02\x00\x00\x00" + b"\x20\x00\x00\x00" + b"\x00" * 20)
+    with pytest.raises(RuntimeError):
+        pt.SceneLoader().load(str(bad))
+
+
+@pytest.mark.parametrize("name", ["box", "duck"])
+def test_host_bvh_equals_oracle_and_golden(pt, box_scene, duck_scene, box_oracle, duck_oracle, name):
+    sc, osc = (box_scene, box_oracle) if name == "box" else (duck_scene, duck_oracle)
+    info, bounds, links, idx = pt.host_bvh_build(sc.triangles)
+    ob_b, ob_l, ob_i, _ = osc.bvh()
+    g = np.load(os.path.join(GOLD, "bvh_%s.npz" % name))
+    for b, l, i in ((ob_b, ob_l, ob_i), (g["bounds"], g["links"], g["indices"])):
+        assert np.array_equal(bounds.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(links, l) and np.array_equal(idx, i)
+    expect = {"box": (21, 11, 5, 6, 3), "duck": (665, 333, 1603, 18, 8)}[name]
+    assert (info["nodes"], info["leaves"], info["max_leaf"], info["depth"], info["max_stack"]) == expect
+
+
+def test_bvh_root_leaf_and_tiny_scenes(pt, ob):
+    """<= 5 triangles: the root is never split and is its own two children (bvh.h:26,:189-190)."""
+    tris = np.zeros(3, pt.capi.TRIANGLE_DTYPE)
+    for k in range(3):
+        tris[k]["v0"]["position"] = (k, 0, -5); tris[k]["v1"]["position"] = (k + 1, 0, -5); tris[k]["v2"]["position"] = (k, 1, -5)
+    info, bounds, links, idx = pt.host_bvh_build(tris)
+    assert info["nodes"] == 1 and links[0].tolist() == [0, 0, 0, 3] and info["max_stack"] == 1
+    mats = np.zeros(1, pt.capi.MATERIAL_DTYPE); mats["emissiveFactor"] = 1
+    mats["baseColorTextureIdx"] = -1; mats["emissiveTextureIdx"] = -1
+    osc = ob.OracleScene(tris, mats)
+    assert np.array_equal(osc.bvh()[1], links)
+    _, _, c = osc.render(((0.5, 0.3, 0), (0, 0, -1), 45, 45), 8, 8, 1, 2)
+    assert c["box_tests"] == 2 * c["segments"]                       # root tested as both of its children
+
+
+def test_fsfl_task_layout_matches_reference_rule(pt):
+    """TaskGenerator::generateEqualTasks (TaskGenerator.h:58-80) over getTaskLayout
+    (RenderManager.h:42-59): rows of <= maxTasksInRow, last column/row absorb remainders."""
+    tg = pt.TaskGenerator()
+    for count, maxrow, W, H in [(1, 2, 400, 400), (2, 2, 1920, 1080), (3, 2, 401, 399), (8, 2, 1920, 1080), (5, 3, 1001, 777)]:
+        layout = pt.get_task_layout(count, maxrow)
+        tasks = tg.generateEqualTasks(count, layout, W, H)
+        cover = np.zeros((H, W), np.int32)
+        th = H // len(layout)
+        for i, row in enumerate(layout):
+            tw = W // len(row)
+            for j, t in enumerate(row):
+                assert tasks[t].offset_x == tw * j and tasks[t].offset_y == th * i
+                assert tasks[t].width == (tw if j < len(row) - 1 else W - tw * j)
+                assert tasks[t].height == (th if i < len(layout) - 1 else H - th * i)
+                cover[tasks[t].offset_y:tasks[t].offset_y + tasks[t].height, tasks[t].offset_x:tasks[t].offset_x + tasks[t].width] += 1
+        assert np.all(cover == 1)
+    row = tg.generateEqualTasks(3, 1000, 50)                         # TaskGenerator.h:46-55
+    assert [(t.width, t.height, t.offset_x, t.offset_y) for t in row] == [(333, 50, 0, 0), (333, 50, 333, 0), (334, 50, 666, 0)]
+
+
+def test_row_bands_cover_the_frame_exactly_once(pt):
+    for W, H, band, n in [(1920, 1080, 8, 8), (64, 36, 8, 3), (400, 400, 16, 5), (32, 6, 8, 4), (1920, 1080, 8, 1)]:
+        cover = np.zeros(H, np.int32)
+        for r in range(n):
+            tasks = pt.row_band_tasks(W, H, band, n, r)
+            ranges = pt.band_row_ranges(H, band, n, r)
+            assert len(tasks) == len(ranges)
+            for t, (r0, r1) in zip(tasks, ranges):
+                assert t.width == W and t.offset_x == 0 and t.height == r1 - r0 and t.offset_y == H - r1
+                assert r0 % 2 == 0                                    # chroma rows stay whole inside a band
+                cover[r0:r1] += 1
+        assert np.all(cover == 1)
+    with pytest.raises(pt.capi.PtError):
+        pt.row_band_tasks(64, 64, 7, 2, 0)                           # odd band height splits chroma rows
+
+
+def test_pack_unpack_bands_roundtrip(pt):
+    rng = np.random.default_rng(0)
+    W, H, band, n = 64, 36, 8, 3
+    total = W * H
+    rgb = rng.integers(0, 256, total * 3, dtype=np.uint8)
+    yuv = rng.integers(0, 256, total + 2 * (total // 4), dtype=np.uint8)
+    out_rgb = np.zeros_like(rgb); out_yuv = np.zeros_like(yuv)
+    for r in range(n):
+        ranges = pt.band_row_ranges(H, band, n, r)
+        packed = pt.pack_bands(rgb, yuv, W, H, ranges, np)
+        assert packed.size == pt.packed_size(W, H, ranges)
+        assert pt.unpack_bands(packed, out_rgb, out_yuv, W, H, ranges) == packed.size
+    assert np.array_equal(out_rgb, rgb) and np.array_equal(out_yuv, yuv)
+
+
+def test_ppm_obj_and_terrain(pt, tmp_path):
+    img = np.arange(4 * 3 * 3, dtype=np.uint8).reshape(3, 4, 3)
+    p = tmp_path / "o.ppm"
+    pt.write_ppm(str(p), img)
+    assert p.read_bytes() == b"P6\n4 3\n255\n" + img.tobytes()
+    (tmp_path / "m.mtl").write_text("newmtl lambertian_grey\nKa 0.3 0.4 0.5\nKd 1 1 1\nnewmtl diffuse_light_top\nKd 2 2 2\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+                                    "usemtl lambertian_grey\nf 1/1 2/2 3/3 4/4\nusemtl diffuse_light_top\nf -4 -3 -2\n")
+    sc = pt.SceneLoader().load(str(tmp_path / "m.obj"))
+    assert len(sc.triangles) == 3 and sc.material_names == ["lambertian_grey", "diffuse_light_top"]
+    assert np.allclose(sc.materials["baseColor"][0], [0.3, 0.4, 0.5]) and sc.materials["emissiveFactor"][1].tolist() == [2, 2, 2]
+    assert sc.triangles["v2"]["texCoords"][1].tolist() == [0, 1]
+    terr = pt.make_terrain_scene(16)
+    assert len(terr.triangles) == 2 * 16 * 16 + 2 and terr.materials["emissiveFactor"][1].tolist() == [1, 1, 1]
+    t2 = pt.make_terrain_scene(16)
+    assert terr.triangles.tobytes() == t2.triangles.tobytes()        # deterministic
+    info, _, links, _ = pt.host_bvh_build(terr.triangles)
+    assert info["max_stack"] <= 64 and links[:, 3].sum() == len(terr.triangles)
+
+
+def test_render_without_gpu_fails_loudly(pt, box_scene):
+    """No CPU fallback: on a box without a GPU creating the engine is an error, not a slow path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    st = pt.capi.lib().pt_device_create(0, C.byref(h))
+    assert st == 8 and b"no CPU fallback" in pt.capi.lib().pt_last_error_string()
