@@ -143,6 +143,12 @@ PT_API pt_status pt_fb_free(pt_device *dev, uint8_t *rgb_device, uint8_t *yuv_de
 PT_API pt_status pt_fb_download(pt_device *dev, const uint8_t *src_device, uint8_t *dst_host,
                                 size_t bytes, pt_stream stream);
 
+/* The explicit gather that replaces UVM page migration in single-process use: copies the
+ * pixels of `task` (RGB rows, Y rows and the U/V samples it owns) from the device framebuffer
+ * bound with pt_bind_framebuffer into full-frame host buffers of the same layout, then waits. */
+PT_API pt_status pt_fb_download_task(pt_device *dev, const pt_task *task, uint8_t *rgb_host,
+                                     uint8_t *yuv_host, pt_stream stream);
+
 /* Device arithmetic self-test (bit-exactness contract): evaluates on the GPU
  * op 0: sincos(x)->(out0,out1); 1: a/b; 2: sqrt(a); 3: (float)((double)a / pi);
  * 4: XORWOW uniform #b (0-based) of seed (uint32)a bits -> out0.                          */

@@ -86,6 +86,7 @@ _PROTOS = {
     "pt_fb_alloc": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
     "pt_fb_free": (C.c_int, [_vp, _vp, _vp]),
     "pt_fb_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "pt_fb_download_task": (C.c_int, [_vp, C.POINTER(Task), _vp, _vp, _vp]),
     "pt_kat_arith": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t]),
     "pt_kat_closest_hit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_size_t]),
     "pt_scene_load_glb": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),

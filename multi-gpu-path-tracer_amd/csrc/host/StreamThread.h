@@ -1,0 +1,69 @@
+// StreamThread.h -- one worker per (GPU, stream), as StreamThread.h:16-115: between the two
+// frame barriers it launches its task on its stream, waits for it, records the wall time in
+// RenderTask::time and (new) copies the task's pixels into the shared host framebuffer.
+// Unlike the reference (tasks_[deviceIdx], StreamThread.h:83) every worker owns task number
+// `taskIdx`, so streamsPerGpu > 1 renders every task exactly once.
+#pragma once
+
+#include <atomic>
+#include <chrono>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "DevicePathTracer.h"
+#include "barrier.h"
+
+namespace ptamd {
+
+class StreamThread {
+public:
+    StreamThread(int device_idx, int task_idx, std::shared_ptr<DevicePathTracer> devicePathTracer,
+                 std::vector<RenderTask> &tasks, Barrier &barrier)
+        : deviceIdx{device_idx}, taskIdx{task_idx}, devicePathTracer{devicePathTracer}, tasks_{tasks}, barrier_{barrier}
+    {
+        stream = devicePathTracer->createStream();
+    }
+
+    ~StreamThread()
+    {
+        shouldTerminate = true;
+        if (thread_.joinable()) thread_.join();
+        devicePathTracer->destroyStream(stream);
+    }
+
+    void start() { thread_ = std::thread(&StreamThread::threadMain, this); }
+    void finish() { shouldTerminate = true; }
+    void join() { if (thread_.joinable()) thread_.join(); }
+
+    void threadMain()
+    {
+        while (true) {
+            barrier_.wait();                       // frame start (RenderManager::renderFrame)
+            if (shouldTerminate) return;
+            if ((size_t)taskIdx < tasks_.size()) {
+                RenderTask &task = tasks_[(size_t)taskIdx];
+                auto start = std::chrono::high_resolution_clock::now();
+                devicePathTracer->renderTaskAsync(task, stream);
+                devicePathTracer->synchronizeStream(stream);
+                auto stop = std::chrono::high_resolution_clock::now();
+                task.time = (int)std::chrono::duration_cast<std::chrono::milliseconds>(stop - start).count();
+                devicePathTracer->gatherTask(task, stream);
+            }
+            barrier_.wait();                       // frame end
+            if (shouldTerminate) return;
+        }
+    }
+
+private:
+    int deviceIdx;
+    int taskIdx;
+    std::atomic_bool shouldTerminate{false};
+    std::shared_ptr<DevicePathTracer> devicePathTracer;
+    pt_stream stream = nullptr;
+    std::thread thread_{};
+    std::vector<RenderTask> &tasks_;
+    Barrier &barrier_;
+};
+
+} // namespace ptamd

@@ -1,0 +1,91 @@
+// main.cpp -- `pt_render`: the .glb -> PPM driver on top of RenderManager, replacing the
+// reference's main.cu:33-95 (whose only sinks are a websocket stream or a GL window).
+//   pt_render <jobId> <model.glb|.obj> [options]      (argv[1], argv[2] as ArgumentLoader.h:10-13)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+
+#include "RenderManager.h"
+
+using namespace ptamd;
+
+static bool parse3(const char *s, Float3 &out) { return sscanf(s, "%f,%f,%f", &out.x, &out.y, &out.z) == 3; }
+
+int main(int argc, char **argv)
+{
+    RendererConfig config;
+    config.jobId = (argc > 1 && argv[1][0] != '\0') ? argv[1] : "0";
+    config.modelPath = (argc > 2 && argv[2][0] != '\0') ? argv[2] : "models/cornell_duck.glb";
+    config.showTasks = false;
+    CameraConfig cameraConfig(Float3{0, 0, 0.5f}, Float3{0, 0, -0.5f});      // main.cu:40
+    std::string out = "out.ppm", yuvOut;
+    int frames = 1;
+    bool cornell = false;
+    for (int i = 3; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "--width") config.resolution.width = (unsigned)atoi(next());
+        else if (a == "--height") config.resolution.height = (unsigned)atoi(next());
+        else if (a == "--spp") config.samplesPerPixel = (unsigned)atoi(next());
+        else if (a == "--depth") config.recursionDepth = (unsigned)atoi(next());
+        else if (a == "--gpus") config.gpuNumber = (unsigned)atoi(next());
+        else if (a == "--streams") config.streamsPerGpu = (unsigned)atoi(next());
+        else if (a == "--max-tasks-in-row") config.maxTasksInRow = (unsigned)atoi(next());
+        else if (a == "--frames") frames = atoi(next());
+        else if (a == "--out") out = next();
+        else if (a == "--yuv") yuvOut = next();
+        else if (a == "--cornell") cornell = true;
+        else if (a == "--show-tasks") config.showTasks = true;
+        else if (a == "--vfov") cameraConfig.vfov = (float)atof(next());
+        else if (a == "--hfov") cameraConfig.hfov = (float)atof(next());
+        else if (a == "--lookfrom") { if (!parse3(next(), cameraConfig.lookFrom)) { std::cerr << "bad --lookfrom\n"; return 2; } }
+        else if (a == "--front") { if (!parse3(next(), cameraConfig.front)) { std::cerr << "bad --front\n"; return 2; } }
+        else if (a == "--algo") {
+            std::string v = next();
+            config.algorithmType = v == "dsfl" ? DSFL : (v == "dsdl" ? DSDL : FSFL);
+        } else { std::cerr << "unknown option " << a << "\n"; return 2; }
+    }
+    if (cornell) { cameraConfig.lookFrom = Float3{-255.5f, 252.5f, 700.0f}; cameraConfig.front = Float3{0, 0, -1}; }
+
+    SceneLoader sceneLoader;
+    HostScene hScene;
+    try {
+        hScene = sceneLoader.load(config.modelPath, cornell);
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << std::endl;
+        return 1;
+    }
+    std::cout << "Number of triangles: " << hScene.triangles.size() << std::endl;
+
+    auto t0 = std::chrono::high_resolution_clock::now();
+    RenderManager manager(config, hScene, cameraConfig, sceneLoader);
+    auto t1 = std::chrono::high_resolution_clock::now();
+    std::cout << "initializing in: " << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << "ms" << std::endl;
+
+    for (int f = 0; f < frames; f++) {
+        for (auto &dpt : manager.tracers()) dpt->resetCounters();
+        auto start = std::chrono::high_resolution_clock::now();
+        manager.renderFrame();
+        auto stop = std::chrono::high_resolution_clock::now();
+        double ms = std::chrono::duration<double, std::milli>(stop - start).count();
+        std::cout << "Path Tracing took: " << (long)ms << "ms" << std::endl;
+        unsigned long long seg = 0;
+        for (auto &dpt : manager.tracers()) seg += dpt->readCounters().segments;
+        printf("{\"frame\": %d, \"ms\": %.3f, \"segments\": %llu, \"segments_per_s\": %.4g, \"imbalance\": %.3f}\n", f, ms, seg,
+               (double)seg / (ms * 1e-3), manager.imbalance());
+    }
+    if (pt_write_ppm(out.c_str(), (int)manager.getCurrentFrameWidth(), (int)manager.getCurrentFrameHeight(), manager.getCurrentFrame()) != PT_OK) {
+        std::cerr << pt_last_error_string() << std::endl;
+        return 1;
+    }
+    if (!yuvOut.empty()) {
+        FILE *fp = fopen(yuvOut.c_str(), "wb");
+        size_t total = (size_t)manager.getCurrentFrameWidth() * manager.getCurrentFrameHeight();
+        if (fp) { fwrite(manager.getYUVFrame(), 1, total + 2 * (total / 4), fp); fclose(fp); }
+    }
+    std::cout << "wrote " << out << std::endl;
+    return 0;
+}

@@ -864,6 +864,39 @@ pt_status pt_fb_download(pt_device *dev, const uint8_t *src, uint8_t *dst, size_
     return PT_OK;
 }
 
+pt_status pt_fb_download_task(pt_device *dev, const pt_task *task, uint8_t *rgb_host, uint8_t *yuv_host, pt_stream stream)
+{
+    clear_error();
+    if (!dev || !task || !rgb_host || !yuv_host) return set_error(PT_ERR_INVALID, "null argument");
+    if (!dev->rgb) return set_error(PT_ERR_NO_SCENE, "no framebuffer bound");
+    if (task->width <= 0 || task->height <= 0) return PT_OK;
+    const int W = dev->W, H = dev->H;
+    if (task->offset_x < 0 || task->offset_y < 0 || task->offset_x + task->width > W || task->offset_y + task->height > H)
+        return set_error(PT_ERR_INVALID, "task rectangle leaves the framebuffer");
+    PT_HIP(hipSetDevice(dev->index));
+    hipStream_t hs = (hipStream_t)stream;
+    const int r0 = H - task->offset_y - task->height, r1 = H - task->offset_y;    // fb rows, 0 = top
+    const int x0 = task->offset_x, x1 = task->offset_x + task->width;
+    size_t off = (size_t)r0 * W * 3 + (size_t)x0 * 3;
+    PT_HIP(hipMemcpy2DAsync(rgb_host + off, (size_t)W * 3, dev->rgb + off, (size_t)W * 3, (size_t)(x1 - x0) * 3,
+                            (size_t)(r1 - r0), hipMemcpyDeviceToHost, hs));
+    off = (size_t)r0 * W + (size_t)x0;
+    PT_HIP(hipMemcpy2DAsync(yuv_host + off, (size_t)W, dev->yuv + off, (size_t)W, (size_t)(x1 - x0), (size_t)(r1 - r0),
+                            hipMemcpyDeviceToHost, hs));
+    const int half = W / 2, total = W * H, uv = total / 4;
+    const int c0 = (r0 + 1) / 2, c1 = std::min((r1 + 1) / 2, H / 2);              // chroma rows of even fb rows
+    const int k0 = (x0 + 1) / 2, k1 = std::min((x1 + 1) / 2, half);               // chroma cols of even fb cols
+    if (c1 > c0 && k1 > k0) {
+        for (int plane = 0; plane < 2; plane++) {
+            size_t o = (size_t)total + (size_t)plane * uv + (size_t)c0 * half + (size_t)k0;
+            PT_HIP(hipMemcpy2DAsync(yuv_host + o, (size_t)half, dev->yuv + o, (size_t)half, (size_t)(k1 - k0),
+                                    (size_t)(c1 - c0), hipMemcpyDeviceToHost, hs));
+        }
+    }
+    PT_HIP(hipStreamSynchronize(hs));
+    return PT_OK;
+}
+
 pt_status pt_kat_arith(pt_device *dev, int op, const float *a, const float *b, float *out0, float *out1, size_t n)
 {
     clear_error();
