@@ -78,53 +78,84 @@ __device__ __forceinline__ void load_tri(const TriIsect *tris, int slot, v3 &v0,
     e2 = mk3(b.z, b.w, c.x);
 }
 
-// BVH::hit, bvh.h:178-246, in the reference's visit order: both children's boxes, then the
-// left leaf's triangles, then the right leaf's, then descend left-first (the reference's
-// near/far test compares two copies of the same value, :193-196,:230).  No distance
-// pruning on boxes.  `stack` is this lane's LDS column (stride = blockDim.x).
-__device__ __forceinline__ Hit traverse(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
-                                        uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
+// Scene accessors: the node and triangle arrays are read either from HBM (through L1/L2) or,
+// when the launch staged them, from LDS (ds_read_b128).
+template <bool kLds>
+struct SceneView {
+    const float4 *nodes;      // NodePair records, 4 x float4 each
+    const float4 *tris;       // TriIsect records, 3 x float4 each
+};
+
+// BVH::hit, bvh.h:178-246, split into two phases per ray segment:
+//   phase A  walks the boxes in the reference's order (both children's boxes per visit,
+//            left-first descent, right sibling pushed on the per-lane LDS stack) and only
+//            RECORDS the leaves it would test, in visit order, in a per-lane LDS queue;
+//   phase B  runs Moller-Trumbore over the queued leaves in that same order.
+// This is the reference's exact sequence of triangle tests (aabb::hit ignores ray_t, so the
+// boxes never depend on earlier triangle results); it only keeps the lanes of a wave in the
+// same code at the same time.  When a lane's queue is full the wave drains (phase B) and
+// resumes phase A where it stopped.
+// `stack` / `queue` are this lane's LDS columns (element stride = `stride` lanes).
+template <bool kLds>
+__device__ __forceinline__ Hit traverse(const SceneView<kLds> S, v3 o, v3 d, float tmin, float tmax0,
+                                        uint32_t *stack, uint2 *queue, int stride, int qcap,
+                                        uint32_t &n_box, uint32_t &n_tri)
 {
     Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
     float tmax = tmax0;
     v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     uint32_t pair = 0;
     int sp = 0;
-    while (true) {
-        const float4 *np = reinterpret_cast<const float4 *>(P.nodes + pair);
-        float4 a = np[0], b = np[1], c = np[2];
-        uint4 l = *reinterpret_cast<const uint4 *>(np + 3);
-        bool ol = box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
-        bool orr = box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
-        n_box += 2;
-        // leaf triangles: left range then right range, one Moller-Trumbore per loop trip
-        uint32_t k0 = l.x, n0 = (ol && l.y) ? l.y : 0u;
-        uint32_t k1 = l.z, n1 = (orr && l.w) ? l.w : 0u;
-        if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
-        while (n0 != 0) {
-            v3 v0, e1, e2;
-            load_tri(P.tris, (int)k0, v0, e1, e2);
+    bool walking = true;
+    while (walking) {
+        // ---------------- phase A: boxes -> leaf queue
+        int qn = 0;
+        while (walking && qn + 2 <= qcap) {
+            const float4 *np = S.nodes + 4 * (size_t)pair;
+            float4 a = np[0], b = np[1], c = np[2];
+            float4 lf = np[3];
+            uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
+            uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
+            bool ol = box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
+            bool orr = box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
+            n_box += 2;
+            if (ol && lcnt) { queue[qn * stride] = make_uint2(llink, lcnt); qn++; }
+            if (orr && rcnt) { queue[qn * stride] = make_uint2(rlink, rcnt); qn++; }
+            bool tl = ol && lcnt == 0, tr = orr && rcnt == 0;
+            if (tl && tr) {
+                stack[sp * stride] = rlink;
+                sp++;
+                pair = llink;
+            } else if (tl) {
+                pair = llink;
+            } else if (tr) {
+                pair = rlink;
+            } else if (sp == 0) {
+                walking = false;
+            } else {
+                sp--;
+                pair = stack[sp * stride];
+            }
+        }
+        // ---------------- phase B: triangles of the queued leaves, in queue order
+        int qi = 0;
+        uint32_t k = 0, n = 0;
+        while (true) {
+            if (n == 0) {
+                if (qi == qn) break;
+                uint2 e = queue[qi * stride];
+                qi++;
+                k = e.x; n = e.y;
+            }
+            const float4 *tp = S.tris + 3 * (size_t)k;
+            float4 ta = tp[0], tb = tp[1];
+            float e2z = reinterpret_cast<const float *>(tp + 2)[0];
             float t, u, v;
             n_tri++;
-            if (tri_hit(v0, e1, e2, o, d, tmin, tmax, t, u, v)) {
-                tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k0;
+            if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
+                tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k;
             }
-            k0++; n0--;
-            if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
-        }
-        bool tl = ol && l.y == 0, tr = orr && l.w == 0;
-        if (tl && tr) {
-            stack[sp * stride] = l.z;
-            sp++;
-            pair = l.x;
-        } else if (tl) {
-            pair = l.x;
-        } else if (tr) {
-            pair = l.z;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            pair = stack[sp * stride];
+            k++; n--;
         }
     }
     return h;
@@ -166,11 +197,58 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+// Dynamic LDS layout of a workgroup: [staged NodePairs][staged TriIsects] (only when the scene
+// is staged) [traversal stacks: stack_entries x blockDim dwords][leaf queues: queue_entries x
+// blockDim uint2].  All sections are 16-byte aligned.
+struct LdsLayout {
+    const float4 *nodes;
+    const float4 *tris;
+    uint32_t *stack;
+    uint2 *queue;
+};
+
+template <bool kLds>
+__device__ __forceinline__ LdsLayout lds_carve(const RenderParams &P, float4 *base, int block)
+{
+    LdsLayout L;
+    size_t off = 0;                                  // in float4 units
+    L.nodes = base;
+    if (kLds) off += (size_t)P.n_pairs * 4;
+    L.tris = base + off;
+    if (kLds) off += (size_t)P.n_tris * 3;
+    L.stack = reinterpret_cast<uint32_t *>(base + off);
+    off += ((size_t)P.stack_entries * block + 3) / 4;
+    L.queue = reinterpret_cast<uint2 *>(base + off);
+    return L;
+}
+
+// Cooperative copy of the node and triangle arrays into LDS (scene fits: Cornell box 2.4 KB).
+template <bool kLds>
+__device__ __forceinline__ SceneView<kLds> stage_scene(const RenderParams &P, float4 *base, int tid, int block)
+{
+    SceneView<kLds> S;
+    if (kLds) {
+        const float4 *gn = reinterpret_cast<const float4 *>(P.nodes);
+        const float4 *gt = reinterpret_cast<const float4 *>(P.tris);
+        const int nn = P.n_pairs * 4, nt = P.n_tris * 3;
+        for (int i = tid; i < nn; i += block) base[i] = gn[i];
+        for (int i = tid; i < nt; i += block) base[nn + i] = gt[i];
+        __syncthreads();
+        S.nodes = base;
+        S.tris = base + nn;
+    } else {
+        S.nodes = reinterpret_cast<const float4 *>(P.nodes);
+        S.tris = reinterpret_cast<const float4 *>(P.tris);
+    }
+    return S;
+}
+
 // render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
 // camera::ray_color (camera.h:49-83) flattened into a per-lane state machine.
+template <bool kLds>
 __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
 {
-    extern __shared__ uint32_t lds_stack[];
+    extern __shared__ float4 lds_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid / kWave;
@@ -181,7 +259,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
     const int x = P.task_ox + i, y = P.task_oy + j;
     const bool in_frame = in_task && x >= 0 && y >= 0 && x < P.W && y < P.H;
     const int pixel_index = (P.H - y - 1) * P.W + x;
-    uint32_t *stack = lds_stack + tid;
+    const LdsLayout L = lds_carve<kLds>(P, lds_raw, kBlock);
+    const SceneView<kLds> S = stage_scene<kLds>(P, lds_raw, tid, kBlock);
+    uint32_t *stack = L.stack + tid;
+    uint2 *queue = L.queue + tid;
 
     xorwow rng;
     xorwow_init(rng, (uint64_t)(long long)(1984 + pixel_index));     // :54 seed, :80 state copy
@@ -209,15 +290,14 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
             need_new = false;
         }
         n_seg++;
-        Hit h = traverse(P, ro, rd, 0.001f, 3.402823466e+38f, stack, kBlock, n_box, n_tri);
+        Hit h = traverse<kLds>(S, ro, rd, 0.001f, 3.402823466e+38f, stack, queue, kBlock, P.queue_entries, n_box, n_tri);
         if (h.slot < 0) {
             col = col + mk3(0.0f, 0.0f, 0.0f) * atten;                // camera.h:78-79
             need_new = true;
             continue;
         }
         // hit_record completion, triangle.h:100-108
-        const float4 *tp = reinterpret_cast<const float4 *>(P.tris + h.slot);
-        float4 tc = tp[2];
+        float4 tc = S.tris[3 * (size_t)h.slot + 2];
         v3 normal = mk3(tc.y, tc.z, tc.w);
         v3 p = ro + h.t * rd;
         const float4 *sp4 = reinterpret_cast<const float4 *>(P.shade + h.slot);
@@ -354,14 +434,17 @@ __global__ void kat_arith_kernel(int op, const float *a, const float *b, float *
 __global__ void kat_hit_kernel(RenderParams P, const float *org, const float *dir, float *t_out,
                                int *face_out, size_t n)
 {
-    extern __shared__ uint32_t lds_stack[];
+    extern __shared__ float4 lds_raw[];
+    const LdsLayout L = lds_carve<false>(P, lds_raw, (int)blockDim.x);
+    const SceneView<false> S = stage_scene<false>(P, lds_raw, (int)threadIdx.x, (int)blockDim.x);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool live = i < n;
     size_t k = live ? i : 0;
     v3 o = mk3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
     v3 d = mk3(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
     uint32_t nb = 0, nt = 0;
-    Hit h = traverse(P, o, d, 0.001f, 3.402823466e+38f, lds_stack + threadIdx.x, (int)blockDim.x, nb, nt);
+    Hit h = traverse<false>(S, o, d, 0.001f, 3.402823466e+38f, L.stack + threadIdx.x, L.queue + threadIdx.x,
+                            (int)blockDim.x, P.queue_entries, nb, nt);
     if (live) {
         t_out[i] = h.slot >= 0 ? h.t : -1.0f;
         int face = -1;
@@ -426,7 +509,9 @@ struct pt_device {
     // scene (host mirrors for introspection)
     RefBvh bvh;
     std::vector<int> light_faces;
-    size_t n_tris = 0;
+    size_t n_tris = 0, n_pairs = 0;
+    bool lds_scene = false;       // node + triangle arrays staged in LDS by every workgroup
+    int queue_entries = 8;        // per-lane leaf queue capacity (phase A -> phase B)
     // framebuffer binding
     int W = 0, H = 0;
     uint8_t *rgb = nullptr, *yuv = nullptr;
@@ -633,6 +718,12 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
     dev->light_faces = lights;
     dev->n_lights = (int)lights.size();
     dev->n_tris = n;
+    dev->n_pairs = pairs.size();
+    // Stage the whole scene in LDS when it is small (Cornell box: 10 pairs + 36 triangles =
+    // 2.4 KB); the queue holds every leaf a ray can meet when the tree is small, else 8.
+    const size_t scene_bytes = pairs.size() * sizeof(NodePair) + n * sizeof(TriIsect);
+    dev->lds_scene = scene_bytes <= 24 * 1024;
+    dev->queue_entries = (int)std::min<uint32_t>(std::max<uint32_t>(dev->bvh.leaves + 1, 4), 12);
     dev->has_scene = true;
     return PT_OK;
 }
@@ -664,6 +755,16 @@ pt_status pt_set_thread_block_size(pt_device *dev, unsigned x, unsigned y)
     return PT_OK;
 }
 
+// Bytes of dynamic LDS for a workgroup of `block` lanes (mirrors dev::lds_carve).
+static size_t lds_bytes(const RenderParams &P, int block, bool stage)
+{
+    size_t f4 = 0;
+    if (stage) f4 += (size_t)P.n_pairs * 4 + (size_t)P.n_tris * 3;
+    f4 += ((size_t)P.stack_entries * block + 3) / 4;
+    f4 += ((size_t)P.queue_entries * block * 2 + 3) / 4;
+    return f4 * 16;
+}
+
 static pt_status fill_params(pt_device *dev, RenderParams &P)
 {
     P.nodes = dev->d_nodes; P.tris = dev->d_tris; P.shade = dev->d_shade; P.lights = dev->d_lights;
@@ -674,6 +775,9 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.light_index_scale = (double)(dev->n_lights - 1) + 0.999999;        // hitable_list.h:24
     P.W = dev->W; P.H = dev->H;
     P.stack_entries = (int)std::max<uint32_t>(dev->bvh.max_stack, 2) - 1;
+    P.n_pairs = (int)dev->n_pairs;
+    P.n_tris = (int)dev->n_tris;
+    P.queue_entries = dev->queue_entries;
     return PT_OK;
 }
 
@@ -699,7 +803,8 @@ pt_status pt_render_task_async(pt_device *dev, const pt_task *task, const pt_cam
     P.spp = (int)spp; P.depth = depth;
     long long tiles = (long long)P.tiles_x * P.tiles_y;
     unsigned blocks = (unsigned)((tiles + dev::kWavesPerBlock - 1) / dev::kWavesPerBlock);
-    size_t lds = (size_t)P.stack_entries * dev::kBlock * sizeof(uint32_t);
+    const bool stage = dev->lds_scene;
+    size_t lds = lds_bytes(P, dev::kBlock, stage);
     hipStream_t hs = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev;
     {
@@ -708,7 +813,8 @@ pt_status pt_render_task_async(pt_device *dev, const pt_task *task, const pt_cam
         else { PT_HIP(hipEventCreate(&ev.first)); PT_HIP(hipEventCreate(&ev.second)); }
     }
     PT_HIP(hipEventRecord(ev.first, hs));
-    hipLaunchKernelGGL(dev::render_kernel, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    if (stage) hipLaunchKernelGGL(dev::render_kernel<true>, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else hipLaunchKernelGGL(dev::render_kernel<false>, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(ev.second, hs));
     {
@@ -935,7 +1041,7 @@ pt_status pt_kat_closest_hit(pt_device *dev, const float *org, const float *dirs
     PT_HIP(hipMemcpy(dorg, org, n * 12, hipMemcpyHostToDevice));
     PT_HIP(hipMemcpy(ddir, dirs, n * 12, hipMemcpyHostToDevice));
     unsigned blocks = (unsigned)((n + 255) / 256);
-    size_t lds = (size_t)P.stack_entries * 256 * sizeof(uint32_t);
+    size_t lds = lds_bytes(P, 256, false);
     hipLaunchKernelGGL(dev::kat_hit_kernel, dim3(blocks), dim3(256), lds, 0, P, dorg, ddir, dt, df, n);
     PT_HIP(hipGetLastError());
     PT_HIP(hipDeviceSynchronize());

@@ -32,6 +32,8 @@ struct RenderParams {
     int spp;
     unsigned depth;
     int stack_entries;                // per-lane LDS stack slots (max_stack - 1)
+    int queue_entries;                // per-lane LDS leaf-queue slots (>= 2)
+    int n_pairs, n_tris;              // array lengths (for LDS staging)
 };
 
 CameraBasis camera_basis(const pt_camera &cfg);
