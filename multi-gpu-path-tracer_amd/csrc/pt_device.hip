@@ -96,10 +96,24 @@ struct SceneView {
 // same code at the same time.  When a lane's queue is full the wave drains (phase B) and
 // resumes phase A where it stopped.
 // `stack` / `queue` are this lane's LDS columns (element stride = `stride` lanes).
-template <bool kLds>
+// Leaf-queue entry: {first slot, triangle count}.  Scenes with < 65536 triangles pack it into
+// one dword (half the LDS), larger scenes use two.
+template <bool kPacked> struct QueueEntry;
+template <> struct QueueEntry<true> {
+    typedef uint32_t type;
+    static __device__ __forceinline__ type make(uint32_t first, uint32_t count) { return first | (count << 16); }
+    static __device__ __forceinline__ void split(type e, uint32_t &first, uint32_t &count) { first = e & 0xFFFFu; count = e >> 16; }
+};
+template <> struct QueueEntry<false> {
+    typedef uint2 type;
+    static __device__ __forceinline__ type make(uint32_t first, uint32_t count) { return make_uint2(first, count); }
+    static __device__ __forceinline__ void split(type e, uint32_t &first, uint32_t &count) { first = e.x; count = e.y; }
+};
+
+template <bool kLds, bool kPacked>
 __device__ __forceinline__ Hit traverse(const SceneView<kLds> S, v3 o, v3 d, float tmin, float tmax0,
-                                        uint32_t *stack, uint2 *queue, int stride, int qcap,
-                                        uint32_t &n_box, uint32_t &n_tri)
+                                        uint32_t *stack, typename QueueEntry<kPacked>::type *queue, int stride,
+                                        int qcap, uint32_t &n_box, uint32_t &n_tri)
 {
     Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
     float tmax = tmax0;
@@ -119,8 +133,8 @@ __device__ __forceinline__ Hit traverse(const SceneView<kLds> S, v3 o, v3 d, flo
             bool ol = box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
             bool orr = box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
             n_box += 2;
-            if (ol && lcnt) { queue[qn * stride] = make_uint2(llink, lcnt); qn++; }
-            if (orr && rcnt) { queue[qn * stride] = make_uint2(rlink, rcnt); qn++; }
+            if (ol && lcnt) { queue[qn * stride] = QueueEntry<kPacked>::make(llink, lcnt); qn++; }
+            if (orr && rcnt) { queue[qn * stride] = QueueEntry<kPacked>::make(rlink, rcnt); qn++; }
             bool tl = ol && lcnt == 0, tr = orr && rcnt == 0;
             if (tl && tr) {
                 stack[sp * stride] = rlink;
@@ -143,9 +157,8 @@ __device__ __forceinline__ Hit traverse(const SceneView<kLds> S, v3 o, v3 d, flo
         while (true) {
             if (n == 0) {
                 if (qi == qn) break;
-                uint2 e = queue[qi * stride];
+                QueueEntry<kPacked>::split(queue[qi * stride], k, n);
                 qi++;
-                k = e.x; n = e.y;
             }
             const float4 *tp = S.tris + 3 * (size_t)k;
             float4 ta = tp[0], tb = tp[1];
@@ -204,7 +217,7 @@ struct LdsLayout {
     const float4 *nodes;
     const float4 *tris;
     uint32_t *stack;
-    uint2 *queue;
+    void *queue;
 };
 
 template <bool kLds>
@@ -218,7 +231,7 @@ __device__ __forceinline__ LdsLayout lds_carve(const RenderParams &P, float4 *ba
     if (kLds) off += (size_t)P.n_tris * 3;
     L.stack = reinterpret_cast<uint32_t *>(base + off);
     off += ((size_t)P.stack_entries * block + 3) / 4;
-    L.queue = reinterpret_cast<uint2 *>(base + off);
+    L.queue = reinterpret_cast<void *>(base + off);
     return L;
 }
 
@@ -245,7 +258,7 @@ __device__ __forceinline__ SceneView<kLds> stage_scene(const RenderParams &P, fl
 
 // render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
 // camera::ray_color (camera.h:49-83) flattened into a per-lane state machine.
-template <bool kLds>
+template <bool kLds, bool kPacked>
 __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
 {
     extern __shared__ float4 lds_raw[];
@@ -261,8 +274,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
     const int pixel_index = (P.H - y - 1) * P.W + x;
     const LdsLayout L = lds_carve<kLds>(P, lds_raw, kBlock);
     const SceneView<kLds> S = stage_scene<kLds>(P, lds_raw, tid, kBlock);
+    typedef typename QueueEntry<kPacked>::type qentry;
     uint32_t *stack = L.stack + tid;
-    uint2 *queue = L.queue + tid;
+    qentry *queue = reinterpret_cast<qentry *>(L.queue) + tid;
 
     xorwow rng;
     xorwow_init(rng, (uint64_t)(long long)(1984 + pixel_index));     // :54 seed, :80 state copy
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
             need_new = false;
         }
         n_seg++;
-        Hit h = traverse<kLds>(S, ro, rd, 0.001f, 3.402823466e+38f, stack, queue, kBlock, P.queue_entries, n_box, n_tri);
+        Hit h = traverse<kLds, kPacked>(S, ro, rd, 0.001f, 3.402823466e+38f, stack, queue, kBlock, P.queue_entries, n_box, n_tri);
         if (h.slot < 0) {
             col = col + mk3(0.0f, 0.0f, 0.0f) * atten;                // camera.h:78-79
             need_new = true;
@@ -443,8 +457,8 @@ __global__ void kat_hit_kernel(RenderParams P, const float *org, const float *di
     v3 o = mk3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
     v3 d = mk3(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
     uint32_t nb = 0, nt = 0;
-    Hit h = traverse<false>(S, o, d, 0.001f, 3.402823466e+38f, L.stack + threadIdx.x, L.queue + threadIdx.x,
-                            (int)blockDim.x, P.queue_entries, nb, nt);
+    Hit h = traverse<false, false>(S, o, d, 0.001f, 3.402823466e+38f, L.stack + threadIdx.x,
+                                   reinterpret_cast<uint2 *>(L.queue) + threadIdx.x, (int)blockDim.x, P.queue_entries, nb, nt);
     if (live) {
         t_out[i] = h.slot >= 0 ? h.t : -1.0f;
         int face = -1;
@@ -511,6 +525,7 @@ struct pt_device {
     std::vector<int> light_faces;
     size_t n_tris = 0, n_pairs = 0;
     bool lds_scene = false;       // node + triangle arrays staged in LDS by every workgroup
+    bool packed_queue = false;    // leaf-queue entries fit one dword (< 65536 triangles)
     int queue_entries = 8;        // per-lane leaf queue capacity (phase A -> phase B)
     // framebuffer binding
     int W = 0, H = 0;
@@ -723,6 +738,7 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
     // 2.4 KB); the queue holds every leaf a ray can meet when the tree is small, else 8.
     const size_t scene_bytes = pairs.size() * sizeof(NodePair) + n * sizeof(TriIsect);
     dev->lds_scene = scene_bytes <= 24 * 1024;
+    dev->packed_queue = n < 65536;
     dev->queue_entries = (int)std::min<uint32_t>(std::max<uint32_t>(dev->bvh.leaves + 1, 4), 12);
     dev->has_scene = true;
     return PT_OK;
@@ -756,12 +772,12 @@ pt_status pt_set_thread_block_size(pt_device *dev, unsigned x, unsigned y)
 }
 
 // Bytes of dynamic LDS for a workgroup of `block` lanes (mirrors dev::lds_carve).
-static size_t lds_bytes(const RenderParams &P, int block, bool stage)
+static size_t lds_bytes(const RenderParams &P, int block, bool stage, bool packed)
 {
     size_t f4 = 0;
     if (stage) f4 += (size_t)P.n_pairs * 4 + (size_t)P.n_tris * 3;
     f4 += ((size_t)P.stack_entries * block + 3) / 4;
-    f4 += ((size_t)P.queue_entries * block * 2 + 3) / 4;
+    f4 += ((size_t)P.queue_entries * block * (packed ? 1 : 2) + 3) / 4;
     return f4 * 16;
 }
 
@@ -803,8 +819,8 @@ pt_status pt_render_task_async(pt_device *dev, const pt_task *task, const pt_cam
     P.spp = (int)spp; P.depth = depth;
     long long tiles = (long long)P.tiles_x * P.tiles_y;
     unsigned blocks = (unsigned)((tiles + dev::kWavesPerBlock - 1) / dev::kWavesPerBlock);
-    const bool stage = dev->lds_scene;
-    size_t lds = lds_bytes(P, dev::kBlock, stage);
+    const bool stage = dev->lds_scene, packed = dev->packed_queue;
+    size_t lds = lds_bytes(P, dev::kBlock, stage, packed);
     hipStream_t hs = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev;
     {
@@ -813,8 +829,10 @@ pt_status pt_render_task_async(pt_device *dev, const pt_task *task, const pt_cam
         else { PT_HIP(hipEventCreate(&ev.first)); PT_HIP(hipEventCreate(&ev.second)); }
     }
     PT_HIP(hipEventRecord(ev.first, hs));
-    if (stage) hipLaunchKernelGGL(dev::render_kernel<true>, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else hipLaunchKernelGGL(dev::render_kernel<false>, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    if (stage && packed) hipLaunchKernelGGL((dev::render_kernel<true, true>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (stage) hipLaunchKernelGGL((dev::render_kernel<true, false>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (packed) hipLaunchKernelGGL((dev::render_kernel<false, true>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else hipLaunchKernelGGL((dev::render_kernel<false, false>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(ev.second, hs));
     {
@@ -1041,7 +1059,7 @@ pt_status pt_kat_closest_hit(pt_device *dev, const float *org, const float *dirs
     PT_HIP(hipMemcpy(dorg, org, n * 12, hipMemcpyHostToDevice));
     PT_HIP(hipMemcpy(ddir, dirs, n * 12, hipMemcpyHostToDevice));
     unsigned blocks = (unsigned)((n + 255) / 256);
-    size_t lds = lds_bytes(P, 256, false);
+    size_t lds = lds_bytes(P, 256, false, false);
     hipLaunchKernelGGL(dev::kat_hit_kernel, dim3(blocks), dim3(256), lds, 0, P, dorg, ddir, dt, df, n);
     PT_HIP(hipGetLastError());
     PT_HIP(hipDeviceSynchronize());
