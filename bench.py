@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=48)
     ap.add_argument("--ppm", default=None, help="write the gathered frame of the last step here")
+    ap.add_argument("--share-of", type=int, default=0,
+                    help="diagnostic (1 GPU): time only rank 0's row bands of an N-rank split, print a "
+                         "diagnostic line instead of the metric line")
     args = ap.parse_args()
 
     import torch
@@ -104,6 +107,22 @@ def main():
                             resolution=pt.Resolution(W, H), showTasks=False)
     cam = pt.CameraConfig(camera[0], camera[1])
     mgr = pt.RenderManager(cfg, scene, cam, device_idx=local_rank, band_rows=args.band_rows)
+
+    if args.share_of > 1 and world == 1:
+        # what one rank of an N-GPU run computes, measured on this GPU alone (no gather)
+        tr = mgr.tracer
+        for _ in range(args.warmup):
+            tr.renderBandsAsync(args.band_rows, args.share_of, 0); tr.waitForRenderTask()
+        tr.resetCounters(); tr.resetKernelTime()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.renderBandsAsync(args.band_rows, args.share_of, 0); tr.waitForRenderTask()
+        dt = (time.perf_counter() - t0) / args.steps
+        kms, n = tr.kernelTime()
+        print(json.dumps({"diagnostic": "share_of", "n_ranks": args.share_of, "ms_per_share": dt * 1e3,
+                          "kernel_ms": kms / n, "segments_per_share": tr.readCounters()["segments"] // args.steps}))
+        return
 
     def sync_all():
         torch.cuda.synchronize()

@@ -105,6 +105,12 @@ PT_API pt_status pt_set_thread_block_size(pt_device *dev, unsigned x, unsigned y
 PT_API pt_status pt_render_task_async(pt_device *dev, const pt_task *task,
                                       const pt_camera *camera, unsigned samples_per_pixel,
                                       unsigned recursion_depth, pt_stream stream);
+/* Multi-GPU form of the above: ONE launch renders every row band owned by
+ * `rank` (bands of band_rows framebuffer rows, band b belongs to rank b % n_ranks -- the tasks
+ * pt_tasks_row_bands enumerates) into the bound full-frame buffers.                       */
+PT_API pt_status pt_render_bands_async(pt_device *dev, int band_rows, int n_ranks, int rank,
+                                       const pt_camera *camera, unsigned samples_per_pixel,
+                                       unsigned recursion_depth, pt_stream stream);
 /* synchronizeStream(cudaStream_t), DevicePathTracer.h:222-226. */
 PT_API pt_status pt_stream_sync(pt_device *dev, pt_stream stream);
 /* waitForRenderTask(), DevicePathTracer.h:216-220. */

@@ -269,7 +269,13 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
     const int tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
     const int i = tile_x * 8 + (lane & 7), j = tile_y * 8 + (lane >> 3);
     const bool in_task = (tile_y < P.tiles_y) && (i < P.task_w) && (j < P.task_h);
-    const int x = P.task_ox + i, y = P.task_oy + j;
+    int x = P.task_ox + i, y = P.task_oy + j;
+    if (P.band_ranks > 0) {
+        // row-band mode (pt_render_bands_async): local row j is row (j % band_rows) of this rank's
+        // (j / band_rows)-th band; band b of the frame (fb rows, 0 = top) belongs to rank b % band_ranks
+        const int fb_row = ((j / P.band_rows) * P.band_ranks + P.band_rank) * P.band_rows + (j % P.band_rows);
+        y = P.H - 1 - fb_row;
+    }
     const bool in_frame = in_task && x >= 0 && y >= 0 && x < P.W && y < P.H;
     const int pixel_index = (P.H - y - 1) * P.W + x;
     const LdsLayout L = lds_carve<kLds>(P, lds_raw, kBlock);
@@ -797,26 +803,8 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     return PT_OK;
 }
 
-pt_status pt_render_task_async(pt_device *dev, const pt_task *task, const pt_camera *camera,
-                               unsigned spp, unsigned depth, pt_stream stream)
+static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream)
 {
-    clear_error();
-    if (!dev || !task || !camera) return set_error(PT_ERR_INVALID, "null argument");
-    if (task->width == 0) return PT_OK;                                  // DevicePathTracer.h:195-196
-    if (!dev->has_scene || !dev->rgb) return set_error(PT_ERR_NO_SCENE, "render before pt_upload_scene / pt_bind_framebuffer");
-    if (task->width < 0 || task->height <= 0 || spp > (1u << 24))
-        return set_error(PT_ERR_INVALID, "bad task rectangle or sample count");
-    // host-side shape check before launching a hand-written kernel
-    if (task->offset_x < 0 || task->offset_y < 0 || task->offset_x + task->width > dev->W ||
-        task->offset_y + task->height > dev->H)
-        return set_error(PT_ERR_INVALID, "task rectangle leaves the framebuffer");
-    PT_HIP(hipSetDevice(dev->index));                                    // :200
-    RenderParams P;
-    fill_params(dev, P);
-    P.cam = camera_basis(*camera);
-    P.task_w = task->width; P.task_h = task->height; P.task_ox = task->offset_x; P.task_oy = task->offset_y;
-    P.tiles_x = (task->width + 7) / 8; P.tiles_y = (task->height + 7) / 8;
-    P.spp = (int)spp; P.depth = depth;
     long long tiles = (long long)P.tiles_x * P.tiles_y;
     unsigned blocks = (unsigned)((tiles + dev::kWavesPerBlock - 1) / dev::kWavesPerBlock);
     const bool stage = dev->lds_scene, packed = dev->packed_queue;
@@ -840,6 +828,55 @@ pt_status pt_render_task_async(pt_device *dev, const pt_task *task, const pt_cam
         dev->pending.push_back(ev);
     }
     return PT_OK;
+}
+
+pt_status pt_render_task_async(pt_device *dev, const pt_task *task, const pt_camera *camera,
+                               unsigned spp, unsigned depth, pt_stream stream)
+{
+    clear_error();
+    if (!dev || !task || !camera) return set_error(PT_ERR_INVALID, "null argument");
+    if (task->width == 0) return PT_OK;                                  // DevicePathTracer.h:195-196
+    if (!dev->has_scene || !dev->rgb) return set_error(PT_ERR_NO_SCENE, "render before pt_upload_scene / pt_bind_framebuffer");
+    if (task->width < 0 || task->height <= 0 || spp > (1u << 24))
+        return set_error(PT_ERR_INVALID, "bad task rectangle or sample count");
+    // host-side shape check before launching a hand-written kernel
+    if (task->offset_x < 0 || task->offset_y < 0 || task->offset_x + task->width > dev->W ||
+        task->offset_y + task->height > dev->H)
+        return set_error(PT_ERR_INVALID, "task rectangle leaves the framebuffer");
+    PT_HIP(hipSetDevice(dev->index));                                    // :200
+    RenderParams P;
+    fill_params(dev, P);
+    P.cam = camera_basis(*camera);
+    P.task_w = task->width; P.task_h = task->height; P.task_ox = task->offset_x; P.task_oy = task->offset_y;
+    P.tiles_x = (task->width + 7) / 8; P.tiles_y = (task->height + 7) / 8;
+    P.band_rows = 0; P.band_ranks = 0; P.band_rank = 0;
+    P.spp = (int)spp; P.depth = depth;
+    return launch_render(dev, P, stream);
+}
+
+pt_status pt_render_bands_async(pt_device *dev, int band_rows, int n_ranks, int rank, const pt_camera *camera,
+                                unsigned spp, unsigned depth, pt_stream stream)
+{
+    clear_error();
+    if (!dev || !camera) return set_error(PT_ERR_INVALID, "null argument");
+    if (!dev->has_scene || !dev->rgb) return set_error(PT_ERR_NO_SCENE, "render before pt_upload_scene / pt_bind_framebuffer");
+    if (band_rows <= 0 || (band_rows & 1) || n_ranks <= 0 || rank < 0 || rank >= n_ranks || spp > (1u << 24))
+        return set_error(PT_ERR_INVALID, "bad row-band request (band_rows must be a positive even number)");
+    PT_HIP(hipSetDevice(dev->index));
+    // local rows = rows of all bands b = rank, rank + n_ranks, ... that start inside the frame
+    const int n_bands = (dev->H + band_rows - 1) / band_rows;
+    int local_rows = 0;
+    for (int b = rank; b < n_bands; b += n_ranks) local_rows += std::min(band_rows, dev->H - b * band_rows);
+    if (local_rows == 0) return PT_OK;
+    RenderParams P;
+    fill_params(dev, P);
+    P.cam = camera_basis(*camera);
+    // a partial last band only ever is the last local band, so rows stay contiguous in j
+    P.task_w = dev->W; P.task_h = local_rows; P.task_ox = 0; P.task_oy = 0;
+    P.tiles_x = (dev->W + 7) / 8; P.tiles_y = (local_rows + 7) / 8;
+    P.band_rows = band_rows; P.band_ranks = n_ranks; P.band_rank = rank;
+    P.spp = (int)spp; P.depth = depth;
+    return launch_render(dev, P, stream);
 }
 
 pt_status pt_stream_sync(pt_device *dev, pt_stream stream)

@@ -29,6 +29,7 @@ struct RenderParams {
     int W, H;                         // Resolution
     int task_w, task_h, task_ox, task_oy;
     int tiles_x, tiles_y;             // 8x8 pixel tiles covering the task
+    int band_rows, band_ranks, band_rank;   // band_ranks > 0: task rows are the rows of the row bands owned by band_rank
     int spp;
     unsigned depth;
     int stack_entries;                // per-lane LDS stack slots (max_stack - 1)

@@ -252,6 +252,12 @@ class DevicePathTracer:
         capi.check(capi.lib().pt_render_task_async(self._h, C.byref(t), C.byref(cam), self.samplesPerPixel_,
                                                    self.recursionDepth_, _stream_ptr(stream)))
 
+    def renderBandsAsync(self, band_rows: int, n_ranks: int, rank: int, stream=None):
+        """All row bands of `rank` in one launch (the multi-GPU share of a frame)."""
+        cam = self.cameraConfig_.as_c()
+        capi.check(capi.lib().pt_render_bands_async(self._h, band_rows, n_ranks, rank, C.byref(cam),
+                                                    self.samplesPerPixel_, self.recursionDepth_, _stream_ptr(stream)))
+
     def waitForRenderTask(self):
         capi.check(capi.lib().pt_device_sync(self._h))
 

@@ -62,25 +62,32 @@ def band_row_ranges(height: int, band_rows: int, n_ranks: int, rank: int):
     return [(b * band_rows, min(height, (b + 1) * band_rows)) for b in range(rank, n_bands, n_ranks)]
 
 
+def _chroma_rows(r0: int, r1: int, height: int, half: int):
+    """Chroma rows owned by framebuffer rows [r0, r1): those of its even rows."""
+    c1 = min((r1 + 1) // 2, (height // 2) if half else 0)
+    c0 = min((r0 + 1) // 2, c1)
+    return c0, c1
+
+
 def pack_bands(rgb_flat, yuv_flat, width: int, height: int, ranges, xp):
-    """Concatenate this rank's band bytes: for each band its RGB rows, Y rows, U rows, V rows.
-    xp = torch or numpy (both offer `cat`/`concatenate` through the wrappers below)."""
+    """This rank's band bytes, plane-major: RGB rows of all its bands, then Y rows, then U rows,
+    then V rows (the chroma rows of a band are those of its even framebuffer rows).
+    xp = torch or numpy."""
     total = width * height
     uv = total // 4
     half = width // 2
-    parts = []
+    rgb_p, y_p, u_p, v_p = [], [], [], []
     for (r0, r1) in ranges:
-        parts.append(rgb_flat[r0 * width * 3:r1 * width * 3])
-        parts.append(yuv_flat[r0 * width:r1 * width])
-        c0, c1 = (r0 + 1) // 2, (r1 + 1) // 2          # chroma rows come from even fb rows
-        c1 = min(c1, (height // 2) if half else 0)
-        c0 = min(c0, c1)
-        parts.append(yuv_flat[total + c0 * half: total + c1 * half])
-        parts.append(yuv_flat[total + uv + c0 * half: total + uv + c1 * half])
-    return xp_cat(parts, xp)
+        rgb_p.append(rgb_flat[r0 * width * 3:r1 * width * 3])
+        y_p.append(yuv_flat[r0 * width:r1 * width])
+        c0, c1 = _chroma_rows(r0, r1, height, half)
+        u_p.append(yuv_flat[total + c0 * half: total + c1 * half])
+        v_p.append(yuv_flat[total + uv + c0 * half: total + uv + c1 * half])
+    return xp_cat(rgb_p + y_p + u_p + v_p, xp)
 
 
 def unpack_bands(packed, rgb_flat, yuv_flat, width: int, height: int, ranges):
+    """Inverse of pack_bands: scatter a rank's packed bands into full-frame buffers."""
     total = width * height
     uv = total // 4
     half = width // 2
@@ -88,14 +95,15 @@ def unpack_bands(packed, rgb_flat, yuv_flat, width: int, height: int, ranges):
     for (r0, r1) in ranges:
         n = (r1 - r0) * width * 3
         rgb_flat[r0 * width * 3:r1 * width * 3] = packed[pos:pos + n]; pos += n
+    for (r0, r1) in ranges:
         n = (r1 - r0) * width
         yuv_flat[r0 * width:r1 * width] = packed[pos:pos + n]; pos += n
-        c0, c1 = (r0 + 1) // 2, (r1 + 1) // 2
-        c1 = min(c1, (height // 2) if half else 0)
-        c0 = min(c0, c1)
-        n = (c1 - c0) * half
-        yuv_flat[total + c0 * half: total + c1 * half] = packed[pos:pos + n]; pos += n
-        yuv_flat[total + uv + c0 * half: total + uv + c1 * half] = packed[pos:pos + n]; pos += n
+    for plane in (0, 1):
+        for (r0, r1) in ranges:
+            c0, c1 = _chroma_rows(r0, r1, height, half)
+            n = (c1 - c0) * half
+            base = total + plane * uv
+            yuv_flat[base + c0 * half: base + c1 * half] = packed[pos:pos + n]; pos += n
     return pos
 
 
@@ -103,9 +111,7 @@ def packed_size(width: int, height: int, ranges) -> int:
     half = width // 2
     n = 0
     for (r0, r1) in ranges:
-        c0, c1 = (r0 + 1) // 2, (r1 + 1) // 2
-        c1 = min(c1, (height // 2) if half else 0)
-        c0 = min(c0, c1)
+        c0, c1 = _chroma_rows(r0, r1, height, half)
         n += (r1 - r0) * width * 4 + 2 * (c1 - c0) * half
     return n
 
@@ -116,6 +122,32 @@ def xp_cat(parts, xp):
     return xp.cat(parts) if parts else xp.zeros(0, dtype=xp.uint8)
 
 
+def _plane_views(rgb_flat, yuv_flat, width: int, height: int, band_rows: int):
+    """The four planes as [n_bands, bytes-per-band] views (needs height % band_rows == 0)."""
+    nb = height // band_rows
+    total = width * height
+    uv = total // 4
+    return (rgb_flat.view(nb, -1), yuv_flat[:total].view(nb, -1),
+            yuv_flat[total:total + uv].view(nb, -1), yuv_flat[total + uv:total + 2 * uv].view(nb, -1))
+
+
+def pack_bands_strided(rgb_flat, yuv_flat, width: int, height: int, band_rows: int, world: int, rank: int):
+    """pack_bands for torch tensors when band_rows divides the height: four strided gathers
+    (same byte layout as pack_bands) instead of one slice per band and plane."""
+    import torch
+    return torch.cat([p[rank::world].reshape(-1) for p in _plane_views(rgb_flat, yuv_flat, width, height, band_rows)])
+
+
+def unpack_bands_strided(packed, rgb_flat, yuv_flat, width: int, height: int, band_rows: int, world: int, rank: int):
+    pos = 0
+    for p in _plane_views(rgb_flat, yuv_flat, width, height, band_rows):
+        dst = p[rank::world]
+        n = dst.shape[0] * dst.shape[1]
+        dst.copy_(packed[pos:pos + n].view(dst.shape[0], dst.shape[1]))
+        pos += n
+    return pos
+
+
 def gather_frame(packed, width: int, height: int, band_rows: int, rgb_flat, yuv_flat, group=None):
     """The path's one exchange step: every rank contributes its packed bands, rank 0
     scatters them into the full frame.  Uses torch.distributed.gather (RCCL on GPUs)."""
@@ -123,19 +155,26 @@ def gather_frame(packed, width: int, height: int, band_rows: int, rgb_flat, yuv_
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    strided = height % band_rows == 0 and width % 2 == 0 and height % 2 == 0
     if world == 1:
         unpack_bands(packed, rgb_flat, yuv_flat, width, height, band_row_ranges(height, band_rows, 1, 0))
         return
     sizes = [packed_size(width, height, band_row_ranges(height, band_rows, world, r)) for r in range(world)]
     cap = max(sizes)
-    send = torch.zeros(cap, dtype=torch.uint8, device=packed.device)
-    send[:packed.numel()] = packed
+    if packed.numel() == cap:
+        send = packed
+    else:
+        send = torch.zeros(cap, dtype=torch.uint8, device=packed.device)
+        send[:packed.numel()] = packed
     recv = [torch.empty(cap, dtype=torch.uint8, device=packed.device) for _ in range(world)] if rank == 0 else None
     dist.gather(send, recv, dst=0, group=group)
     if rank == 0:
-        for r in range(world):
-            unpack_bands(recv[r][:sizes[r]], rgb_flat, yuv_flat, width, height,
-                         band_row_ranges(height, band_rows, world, r))
+        for r in range(1, world):          # rank 0's own bands are already in place
+            if strided:
+                unpack_bands_strided(recv[r][:sizes[r]], rgb_flat, yuv_flat, width, height, band_rows, world, r)
+            else:
+                unpack_bands(recv[r][:sizes[r]], rgb_flat, yuv_flat, width, height,
+                             band_row_ranges(height, band_rows, world, r))
 
 
 class RenderManager:
@@ -194,9 +233,12 @@ class RenderManager:
         return self.framebuffer_
 
     def renderTasks(self):
-        """Launch this rank's tasks (StreamThread::threadMain, StreamThread.h:83-84)."""
-        for i, task in enumerate(self.renderTasks_):
-            self.tracer.renderTaskAsync(task, self.streams[i % len(self.streams)])
+        """Launch this rank's share of the frame (StreamThread::threadMain, StreamThread.h:83-84):
+        ONE kernel launch covering all of its row bands."""
+        if self.world == 1:
+            self.tracer.renderTaskAsync(self.renderTasks_[0], self.streams[0])
+        else:
+            self.tracer.renderBandsAsync(self.band_rows, self.world, self.rank, self.streams[0])
 
     def synchronize(self):
         for s in self.streams:
@@ -208,8 +250,12 @@ class RenderManager:
         self.synchronize()
         if gather and self.world > 1:
             res = self.config_.resolution
-            packed = pack_bands(self.framebuffer_.rgb, self.framebuffer_.yuv, res.width, res.height,
-                                self.ranges_, self._torch)
+            if res.height % self.band_rows == 0:
+                packed = pack_bands_strided(self.framebuffer_.rgb, self.framebuffer_.yuv, res.width, res.height,
+                                            self.band_rows, self.world, self.rank)
+            else:
+                packed = pack_bands(self.framebuffer_.rgb, self.framebuffer_.yuv, res.width, res.height,
+                                    self.ranges_, self._torch)
             gather_frame(packed, res.width, res.height, self.band_rows, self.framebuffer_.rgb,
                          self.framebuffer_.yuv)
         self.last_frame_ms = (time.perf_counter() - t0) * 1e3

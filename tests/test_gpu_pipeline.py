@@ -62,6 +62,28 @@ def test_band_tasks_on_several_streams_equal_whole_frame(pt, duck_scene, duck_or
     tr.close()
 
 
+@pytest.mark.parametrize("W,H,band,world", [(64, 36, 8, 3), (100, 50, 4, 4), (64, 64, 16, 2)])
+def test_single_launch_bands_equal_whole_frame(pt, box_scene, box_oracle, gpu_device, W, H, band, world):
+    """pt_render_bands_async: one launch per rank covering all its bands (incl. a partial last
+    band) -- union over ranks == oracle frame; each rank touches only its own rows."""
+    spp, depth = 3, 4
+    ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
+    tr.renderBandsAsync(band, world, 1)
+    tr.waitForRenderTask()
+    mine = pt.band_row_ranges(H, band, world, 1)
+    img = fb.rgb_host()
+    for r in range(H):
+        owned = any(a <= r < b for a, b in mine)
+        assert np.array_equal(img[r], ref[0][r]) if owned else not img[r].any()
+    for rank in (0, 2, 3)[:world - 1]:
+        tr.renderBandsAsync(band, world, rank)
+    tr.waitForRenderTask()
+    assert np.array_equal(fb.rgb_host(), ref[0]) and np.array_equal(fb.yuv_host(), ref[1])
+    tr.close()
+
+
 def _read_ppm(path):
     b = open(path, "rb").read()
     magic, dims, mx, data = b.split(b"\n", 3)

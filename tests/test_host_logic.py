@@ -165,6 +165,23 @@ def test_pack_unpack_bands_roundtrip(pt):
     assert np.array_equal(out_rgb, rgb) and np.array_equal(out_yuv, yuv)
 
 
+def test_strided_pack_equals_generic_pack(pt):
+    import torch
+    rng = np.random.default_rng(1)
+    for W, H, band, n in [(64, 40, 8, 3), (32, 16, 2, 4), (1920, 1080, 8, 8)]:
+        total = W * H
+        rgb = torch.from_numpy(rng.integers(0, 256, total * 3, dtype=np.uint8))
+        yuv = torch.from_numpy(rng.integers(0, 256, total + 2 * (total // 4), dtype=np.uint8))
+        out_rgb = torch.zeros_like(rgb); out_yuv = torch.zeros_like(yuv)
+        for r in range(n):
+            ranges = pt.band_row_ranges(H, band, n, r)
+            a = pt.pack_bands(rgb, yuv, W, H, ranges, torch)
+            b = pt.pack_bands_strided(rgb, yuv, W, H, band, n, r)
+            assert torch.equal(a, b)
+            assert pt.unpack_bands_strided(b, out_rgb, out_yuv, W, H, band, n, r) == b.numel()
+        assert torch.equal(out_rgb, rgb) and torch.equal(out_yuv, yuv)
+
+
 def test_ppm_obj_and_terrain(pt, tmp_path):
     img = np.arange(4 * 3 * 3, dtype=np.uint8).reshape(3, 4, 3)
     p = tmp_path / "o.ppm"
