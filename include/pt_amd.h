@@ -100,6 +100,10 @@ PT_API pt_status pt_bind_framebuffer(pt_device *dev, int width, int height,
                                      uint8_t *rgb_device, uint8_t *yuv_device);
 /* setThreadBlockSize(dim3), DevicePathTracer.h:368: a hint (pixel-tile shape per wave). */
 PT_API pt_status pt_set_thread_block_size(pt_device *dev, unsigned x, unsigned y);
+/* Traversal strategy of the render kernel (same results, different schedule):
+ * 0 = auto, 1 = per-lane two-phase walk (any scene), 2 = wave-uniform walk from the scalar
+ * cache (trees of <= 64 inner nodes, e.g. both Cornell-box models' box part).            */
+PT_API pt_status pt_set_traversal_mode(pt_device *dev, int mode);
 /* renderTaskAsync(RenderTask&, cudaStream_t), DevicePathTracer.h:194-214: no-op when
  * task->width == 0; asynchronous on `stream`; camera by value as at :210.               */
 PT_API pt_status pt_render_task_async(pt_device *dev, const pt_task *task,

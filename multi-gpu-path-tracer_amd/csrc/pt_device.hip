@@ -174,6 +174,57 @@ __device__ __forceinline__ Hit traverse(const SceneView<kLds> S, v3 o, v3 d, flo
     return h;
 }
 
+// Wave-uniform traversal for scenes whose whole tree is at most 64 inner nodes (Cornell box:
+// 10).  All lanes of the wave walk the SAME node / triangle at the same time, in the
+// reference's visit order (NodePairs are numbered in DFS pre-order = visit order), each lane
+// carrying a 64-bit "this pair is on my path" mask instead of a stack.  Because the loop
+// counters are wave-uniform, node and triangle records arrive through the scalar cache
+// (s_load) and sit in SGPRs as instruction operands: no LDS, no per-lane queue, no divergent
+// loop trip counts.  A pair (or a leaf) that no lane of the wave reaches is skipped with one
+// scalar branch.  Per lane the sequence of slab and triangle tests is exactly bvh.h:178-246.
+__device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
+                                                uint32_t &n_box, uint32_t &n_tri)
+{
+    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+    float tmax = tmax0;
+    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
+    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
+    unsigned long long act = 1ull;                       // bit p: pair p is on this lane's path
+    const int n_pairs = P.n_pairs;
+    for (int p = 0; p < n_pairs; p++) {
+        const bool on = (act >> p) & 1ull;
+        if (__ballot(on) == 0ull) continue;              // nobody in the wave visits pair p
+        const float4 a = nodes[4 * p], b = nodes[4 * p + 1], c = nodes[4 * p + 2], lf = nodes[4 * p + 3];
+        const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
+        const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
+        const bool hl = on && box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
+        const bool hr = on && box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
+        if (on) n_box += 2;
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const bool hit = side ? hr : hl;
+            const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
+            if (cnt == 0) {                              // inner child: mark its pair
+                if (hit) act |= 1ull << link;
+            } else if (__ballot(hit) != 0ull) {          // leaf child somebody hits
+                for (uint32_t k = link; k < link + cnt; k++) {
+                    const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
+                    const float e2z = reinterpret_cast<const float *>(tris + 3 * k + 2)[0];
+                    if (hit) {
+                        float t, u, v;
+                        n_tri++;
+                        if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
+                            tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return h;
+}
+
 // BaseColorTexture::value + pixel_data, Texture.h:30-69.  The reference reads row `height`
 // (one past the end) when j == 0; that row is clamped to height-1 here.
 __device__ __forceinline__ v3 tex_value(const RenderParams &P, int tex, float u, float v)
@@ -258,7 +309,7 @@ __device__ __forceinline__ SceneView<kLds> stage_scene(const RenderParams &P, fl
 
 // render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
 // camera::ray_color (camera.h:49-83) flattened into a per-lane state machine.
-template <bool kLds, bool kPacked>
+template <bool kLds, bool kPacked, bool kUniform>
 __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
 {
     extern __shared__ float4 lds_raw[];
@@ -310,7 +361,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
             need_new = false;
         }
         n_seg++;
-        Hit h = traverse<kLds, kPacked>(S, ro, rd, 0.001f, 3.402823466e+38f, stack, queue, kBlock, P.queue_entries, n_box, n_tri);
+        Hit h = kUniform ? traverse_uniform(P, ro, rd, 0.001f, 3.402823466e+38f, n_box, n_tri)
+                         : traverse<kLds, kPacked>(S, ro, rd, 0.001f, 3.402823466e+38f, stack, queue, kBlock, P.queue_entries, n_box, n_tri);
         if (h.slot < 0) {
             col = col + mk3(0.0f, 0.0f, 0.0f) * atten;                // camera.h:78-79
             need_new = true;
@@ -532,6 +584,8 @@ struct pt_device {
     size_t n_tris = 0, n_pairs = 0;
     bool lds_scene = false;       // node + triangle arrays staged in LDS by every workgroup
     bool packed_queue = false;    // leaf-queue entries fit one dword (< 65536 triangles)
+    bool uniform_walk = false;    // <= 64 inner nodes: wave-uniform traversal from the scalar cache
+    int force_walk = -1;          // test hook: -1 auto, 0 per-lane, 1 uniform (when legal)
     int queue_entries = 8;        // per-lane leaf queue capacity (phase A -> phase B)
     // framebuffer binding
     int W = 0, H = 0;
@@ -671,7 +725,20 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
     // flatten: inner nodes -> NodePair records, triangles -> leaf order
     std::vector<uint32_t> pair_of(bvh.nodes.size(), 0xFFFFFFFFu);
     uint32_t n_pairs = 0;
-    for (size_t i = 0; i < bvh.nodes.size(); i++) if (bvh.nodes[i].triCount == 0) pair_of[i] = n_pairs++;
+    {
+        // number the inner nodes in DFS pre-order (node, left subtree, right subtree) = the order in
+        // which the reference traversal can reach them; child links therefore always point forward
+        std::vector<uint32_t> todo;
+        if (bvh.nodes[0].triCount == 0) todo.push_back(0);
+        while (!todo.empty()) {
+            uint32_t id = todo.back();
+            todo.pop_back();
+            pair_of[id] = n_pairs++;
+            const RefNode &nd = bvh.nodes[id];
+            if (bvh.nodes[nd.right].triCount == 0) todo.push_back(nd.right);
+            if (bvh.nodes[nd.left].triCount == 0) todo.push_back(nd.left);
+        }
+    }
     bool root_leaf = bvh.nodes[0].triCount != 0;
     std::vector<NodePair> pairs(root_leaf ? 1 : n_pairs);
     auto fill_child = [&](const RefNode &c, uint32_t ci, float *box6, uint32_t &link, uint32_t &cnt) {
@@ -745,6 +812,7 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
     const size_t scene_bytes = pairs.size() * sizeof(NodePair) + n * sizeof(TriIsect);
     dev->lds_scene = scene_bytes <= 24 * 1024;
     dev->packed_queue = n < 65536;
+    dev->uniform_walk = pairs.size() <= 64 && dev->force_walk != 0;
     dev->queue_entries = (int)std::min<uint32_t>(std::max<uint32_t>(dev->bvh.leaves + 1, 4), 12);
     dev->has_scene = true;
     return PT_OK;
@@ -766,6 +834,17 @@ pt_status pt_bind_framebuffer(pt_device *dev, int width, int height, uint8_t *rg
     if ((width | height) & 1)
         return set_error(PT_ERR_UNSUPPORTED, "odd framebuffer sizes: the reference's YUV420 indexing (DevicePathTracer.h:107-119) writes past its planes; only even widths and heights are accepted");
     dev->W = width; dev->H = height; dev->rgb = rgb; dev->yuv = yuv;
+    return PT_OK;
+}
+
+pt_status pt_set_traversal_mode(pt_device *dev, int mode)
+{
+    clear_error();
+    if (!dev || mode < 0 || mode > 2) return set_error(PT_ERR_INVALID, "mode must be 0 (auto), 1 (per-lane) or 2 (wave-uniform)");
+    dev->force_walk = mode == 0 ? -1 : (mode == 1 ? 0 : 1);
+    if (dev->has_scene) dev->uniform_walk = dev->n_pairs <= 64 && dev->force_walk != 0;
+    if (mode == 2 && dev->has_scene && !dev->uniform_walk)
+        return set_error(PT_ERR_UNSUPPORTED, "wave-uniform traversal needs a tree of at most 64 inner nodes");
     return PT_OK;
 }
 
@@ -807,8 +886,9 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
 {
     long long tiles = (long long)P.tiles_x * P.tiles_y;
     unsigned blocks = (unsigned)((tiles + dev::kWavesPerBlock - 1) / dev::kWavesPerBlock);
-    const bool stage = dev->lds_scene, packed = dev->packed_queue;
-    size_t lds = lds_bytes(P, dev::kBlock, stage, packed);
+    const bool uniform = dev->uniform_walk;
+    const bool stage = dev->lds_scene && !uniform, packed = dev->packed_queue;
+    size_t lds = uniform ? 0 : lds_bytes(P, dev::kBlock, stage, packed);
     hipStream_t hs = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev;
     {
@@ -817,10 +897,11 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         else { PT_HIP(hipEventCreate(&ev.first)); PT_HIP(hipEventCreate(&ev.second)); }
     }
     PT_HIP(hipEventRecord(ev.first, hs));
-    if (stage && packed) hipLaunchKernelGGL((dev::render_kernel<true, true>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else if (stage) hipLaunchKernelGGL((dev::render_kernel<true, false>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else if (packed) hipLaunchKernelGGL((dev::render_kernel<false, true>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else hipLaunchKernelGGL((dev::render_kernel<false, false>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    if (uniform) hipLaunchKernelGGL((dev::render_kernel<false, true, true>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (stage && packed) hipLaunchKernelGGL((dev::render_kernel<true, true, false>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (stage) hipLaunchKernelGGL((dev::render_kernel<true, false, false>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (packed) hipLaunchKernelGGL((dev::render_kernel<false, true, false>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else hipLaunchKernelGGL((dev::render_kernel<false, false, false>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(ev.second, hs));
     {

@@ -288,6 +288,10 @@ class DevicePathTracer:
         self.threadBlockSize_ = tuple(threadBlockSize)
         capi.check(capi.lib().pt_set_thread_block_size(self._h, *self.threadBlockSize_))
 
+    def setTraversalMode(self, mode: int):
+        """0 auto, 1 per-lane walk, 2 wave-uniform walk (small trees only)."""
+        capi.check(capi.lib().pt_set_traversal_mode(self._h, mode))
+
     # -- additions: exact work counters and kernel time (the metric's inputs)
     def readCounters(self) -> dict:
         c = capi.Counters()

@@ -12,10 +12,11 @@ from conftest import BOX_CAMERA, DUCK_CAMERA
 pytestmark = pytest.mark.gpu
 
 
-def _render_gpu(pt, scene, camera, W, H, spp, depth, tasks=None, device=0):
+def _render_gpu(pt, scene, camera, W, H, spp, depth, tasks=None, device=0, mode=0):
     cam = pt.CameraConfig(camera[0], camera[1], camera[2], camera[3])
     fb = pt.Framebuffer(pt.Resolution(W, H), device="cuda:%d" % device)
     tracer = pt.DevicePathTracer(device, spp, depth, (8, 8), scene, fb, cam)
+    tracer.setTraversalMode(mode)
     tracer.resetCounters()
     for t in (tasks or [pt.RenderTask(W, H, 0, 0)]):
         tracer.renderTaskAsync(t)
@@ -106,10 +107,22 @@ def test_closest_hit_matches_oracle_on_random_rays(pt, box_scene, duck_scene, bo
     tr.close()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("W,H,spp,depth", [(64, 64, 4, 4), (200, 120, 8, 8), (50, 34, 3, 1)])
-def test_cornell_box_image_bit_exact(pt, box_scene, box_oracle, gpu_device, W, H, spp, depth):
+def test_cornell_box_image_bit_exact(pt, box_scene, box_oracle, gpu_device, W, H, spp, depth, mode):
+    """Both traversal schedules (1 = per-lane two-phase walk, 2 = wave-uniform walk) must give the
+    oracle's bytes AND the oracle's exact test counts."""
     ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
-    _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, W, H, spp, depth), ref)
+    _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, W, H, spp, depth, mode=mode), ref)
+
+
+def test_wave_uniform_mode_is_refused_for_big_trees(pt, duck_scene, gpu_device):
+    fb = pt.Framebuffer(pt.Resolution(8, 8))
+    tr = pt.DevicePathTracer(0, 1, 1, (8, 8), duck_scene, fb, pt.CameraConfig(DUCK_CAMERA[0], DUCK_CAMERA[1]))
+    with pytest.raises(pt.capi.PtError) as e:
+        tr.setTraversalMode(2)          # 332 inner nodes > 64
+    assert e.value.status == 6
+    tr.close()
 
 
 def test_cornell_box_config1_400x400_16spp_4bounce(pt, box_scene, box_oracle, gpu_device):
