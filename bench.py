@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=48)
     ap.add_argument("--ppm", default=None, help="write the gathered frame of the last step here")
+    ap.add_argument("--width", type=int, default=0, help="diagnostic: override the config's width")
+    ap.add_argument("--height", type=int, default=0, help="diagnostic: override the config's height")
     ap.add_argument("--share-of", type=int, default=0,
                     help="diagnostic (1 GPU): time only rank 0's row bands of an N-rank split, print a "
                          "diagnostic line instead of the metric line")
@@ -102,6 +104,9 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     kind, W, H, spp, depth, desc = CONFIGS[args.config]
+    if args.width or args.height:
+        W, H = args.width or W, args.height or H
+        desc += " [diagnostic size %dx%d]" % (W, H)
     scene, camera = load_scene(pt, kind)
     cfg = pt.RendererConfig(samplesPerPixel=spp, recursionDepth=depth, gpuNumber=world,
                             resolution=pt.Resolution(W, H), showTasks=False)
