@@ -100,9 +100,10 @@ PT_API pt_status pt_bind_framebuffer(pt_device *dev, int width, int height,
                                      uint8_t *rgb_device, uint8_t *yuv_device);
 /* setThreadBlockSize(dim3), DevicePathTracer.h:368: a hint (pixel-tile shape per wave). */
 PT_API pt_status pt_set_thread_block_size(pt_device *dev, unsigned x, unsigned y);
-/* Traversal strategy of the render kernel (same results, different schedule):
- * 0 = auto, 1 = per-lane two-phase walk (any scene), 2 = wave-uniform walk from the scalar
- * cache (trees of <= 64 inner nodes, e.g. both Cornell-box models' box part).            */
+/* Traversal schedule of the render kernel (same results and test counts, different order of
+ * work across the lanes of a wave): 0 = auto, 1 = per-lane two-phase walk (any
+ * scene), 2 = wave-uniform walk with a 64-bit path mask (trees of <= 64 inner nodes),
+ * 3 = wave-uniform walk with a per-lane LDS stack (<= 4096 inner nodes).                  */
 PT_API pt_status pt_set_traversal_mode(pt_device *dev, int mode);
 /* renderTaskAsync(RenderTask&, cudaStream_t), DevicePathTracer.h:194-214: no-op when
  * task->width == 0; asynchronous on `stream`; camera by value as at :210.               */

@@ -225,6 +225,75 @@ __device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 
     return h;
 }
 
+// The same wave-uniform walk for bigger trees (cornell_duck: 332 inner nodes, leaves of up to
+// 1603 triangles): instead of a 64-bit mask each lane keeps the NEXT pair on its path plus its
+// pending right siblings on the per-lane LDS stack.  Pairs are numbered in visit order, so the
+// pending set is a stack and `next` is always its minimum; the wave scans p upward and a lane
+// takes part in pair p iff next == p.  Leaves are tested in lockstep by every lane that hit
+// their box, with triangle records coming through the scalar cache -- a 1603-triangle leaf costs
+// 1603 uniform trips instead of 1603 divergent gather trips per lane.  Cost per ray segment is
+// the UNION of the lanes' paths, so the host picks this walk only for small / medium trees.
+__device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
+                                                      uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
+{
+    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+    float tmax = tmax0;
+    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
+    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
+    uint32_t next = 0;
+    int sp = 0;
+    bool walking = true;
+    const int n_pairs = P.n_pairs;
+    for (int p = 0; p < n_pairs; p++) {
+        const bool on = walking && next == (uint32_t)p;
+        if (__ballot(on) == 0ull) {
+            if (__ballot(walking) == 0ull) break;        // every lane of the wave is done
+            continue;
+        }
+        const float4 a = nodes[4 * p], b = nodes[4 * p + 1], c = nodes[4 * p + 2], lf = nodes[4 * p + 3];
+        const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
+        const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
+        const bool hl = on && box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
+        const bool hr = on && box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
+        if (on) {
+            n_box += 2;
+            const bool tl = hl && lcnt == 0, tr = hr && rcnt == 0;
+            if (tl && tr) {
+                stack[sp * stride] = rlink;
+                sp++;
+                next = llink;
+            } else if (tl || tr) {
+                next = tl ? llink : rlink;
+            } else if (sp == 0) {
+                walking = false;
+            } else {
+                sp--;
+                next = stack[sp * stride];
+            }
+        }
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const bool hit = side ? hr : hl;
+            const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
+            if (cnt != 0 && __ballot(hit) != 0ull) {
+                for (uint32_t k = link; k < link + cnt; k++) {
+                    const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
+                    const float e2z = reinterpret_cast<const float *>(tris + 3 * k + 2)[0];
+                    if (hit) {
+                        float t, u, v;
+                        n_tri++;
+                        if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
+                            tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return h;
+}
+
 // BaseColorTexture::value + pixel_data, Texture.h:30-69.  The reference reads row `height`
 // (one past the end) when j == 0; that row is clamped to height-1 here.
 __device__ __forceinline__ v3 tex_value(const RenderParams &P, int tex, float u, float v)
@@ -309,7 +378,9 @@ __device__ __forceinline__ SceneView<kLds> stage_scene(const RenderParams &P, fl
 
 // render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
 // camera::ray_color (camera.h:49-83) flattened into a per-lane state machine.
-template <bool kLds, bool kPacked, bool kUniform>
+// kWalk: 0 = per-lane two-phase walk, 1 = wave-uniform walk with a 64-bit path mask (<= 64 inner
+// nodes), 2 = wave-uniform walk with the per-lane LDS stack (medium trees).
+template <bool kLds, bool kPacked, int kWalk>
 __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
 {
     extern __shared__ float4 lds_raw[];
@@ -361,8 +432,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
             need_new = false;
         }
         n_seg++;
-        Hit h = kUniform ? traverse_uniform(P, ro, rd, 0.001f, 3.402823466e+38f, n_box, n_tri)
-                         : traverse<kLds, kPacked>(S, ro, rd, 0.001f, 3.402823466e+38f, stack, queue, kBlock, P.queue_entries, n_box, n_tri);
+        Hit h;
+        if (kWalk == 1) h = traverse_uniform(P, ro, rd, 0.001f, 3.402823466e+38f, n_box, n_tri);
+        else if (kWalk == 2) h = traverse_uniform_stack(P, ro, rd, 0.001f, 3.402823466e+38f, stack, kBlock, n_box, n_tri);
+        else h = traverse<kLds, kPacked>(S, ro, rd, 0.001f, 3.402823466e+38f, stack, queue, kBlock, P.queue_entries, n_box, n_tri);
         if (h.slot < 0) {
             col = col + mk3(0.0f, 0.0f, 0.0f) * atten;                // camera.h:78-79
             need_new = true;
@@ -584,8 +657,8 @@ struct pt_device {
     size_t n_tris = 0, n_pairs = 0;
     bool lds_scene = false;       // node + triangle arrays staged in LDS by every workgroup
     bool packed_queue = false;    // leaf-queue entries fit one dword (< 65536 triangles)
-    bool uniform_walk = false;    // <= 64 inner nodes: wave-uniform traversal from the scalar cache
-    int force_walk = -1;          // test hook: -1 auto, 0 per-lane, 1 uniform (when legal)
+    int walk = 0;                 // traversal schedule: 0 per-lane, 1 uniform/mask, 2 uniform/stack
+    int force_walk = -1;          // pt_set_traversal_mode: -1 auto, else the requested schedule
     int queue_entries = 8;        // per-lane leaf queue capacity (phase A -> phase B)
     // framebuffer binding
     int W = 0, H = 0;
@@ -597,6 +670,18 @@ struct pt_device {
     double ms_total = 0.0;
     uint64_t launches = 0;
 };
+
+// Traversal schedule for the uploaded tree.  The wave-uniform walks cost the UNION of the 64
+// lanes' paths per ray segment, which is fine while the tree is small (incoherent rays touch
+// most of it anyway under the reference's no-pruning traversal) and ruinous for big trees.
+static int choose_walk(const pt_device *d)
+{
+    const bool mask_ok = d->n_pairs <= 64, stack_ok = d->n_pairs <= 4096;
+    if (d->force_walk == 0) return 0;
+    if (d->force_walk == 1) return mask_ok ? 1 : -1;
+    if (d->force_walk == 2) return stack_ok ? 2 : -1;
+    return mask_ok ? 1 : (stack_ok ? 2 : 0);
+}
 
 static void free_scene(pt_device *d)
 {
@@ -812,7 +897,7 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
     const size_t scene_bytes = pairs.size() * sizeof(NodePair) + n * sizeof(TriIsect);
     dev->lds_scene = scene_bytes <= 24 * 1024;
     dev->packed_queue = n < 65536;
-    dev->uniform_walk = pairs.size() <= 64 && dev->force_walk != 0;
+    dev->walk = choose_walk(dev);
     dev->queue_entries = (int)std::min<uint32_t>(std::max<uint32_t>(dev->bvh.leaves + 1, 4), 12);
     dev->has_scene = true;
     return PT_OK;
@@ -840,11 +925,17 @@ pt_status pt_bind_framebuffer(pt_device *dev, int width, int height, uint8_t *rg
 pt_status pt_set_traversal_mode(pt_device *dev, int mode)
 {
     clear_error();
-    if (!dev || mode < 0 || mode > 2) return set_error(PT_ERR_INVALID, "mode must be 0 (auto), 1 (per-lane) or 2 (wave-uniform)");
-    dev->force_walk = mode == 0 ? -1 : (mode == 1 ? 0 : 1);
-    if (dev->has_scene) dev->uniform_walk = dev->n_pairs <= 64 && dev->force_walk != 0;
-    if (mode == 2 && dev->has_scene && !dev->uniform_walk)
-        return set_error(PT_ERR_UNSUPPORTED, "wave-uniform traversal needs a tree of at most 64 inner nodes");
+    if (!dev || mode < 0 || mode > 3) return set_error(PT_ERR_INVALID, "mode must be 0 (auto), 1 (per-lane), 2 (wave-uniform, mask) or 3 (wave-uniform, stack)");
+    const int saved = dev->force_walk;
+    dev->force_walk = mode - 1;                 // -1 auto, 0 per-lane, 1 mask, 2 stack
+    if (dev->has_scene) {
+        int w = choose_walk(dev);
+        if (w < 0) {
+            dev->force_walk = saved;
+            return set_error(PT_ERR_UNSUPPORTED, "this tree is too big for the requested wave-uniform walk (mask: <= 64 inner nodes, stack: <= 4096)");
+        }
+        dev->walk = w;
+    }
     return PT_OK;
 }
 
@@ -886,9 +977,10 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
 {
     long long tiles = (long long)P.tiles_x * P.tiles_y;
     unsigned blocks = (unsigned)((tiles + dev::kWavesPerBlock - 1) / dev::kWavesPerBlock);
-    const bool uniform = dev->uniform_walk;
-    const bool stage = dev->lds_scene && !uniform, packed = dev->packed_queue;
-    size_t lds = uniform ? 0 : lds_bytes(P, dev::kBlock, stage, packed);
+    const int walk = dev->walk;
+    const bool stage = dev->lds_scene && walk == 0, packed = dev->packed_queue;
+    if (walk == 2) P.queue_entries = 0;
+    size_t lds = walk == 1 ? 0 : lds_bytes(P, dev::kBlock, stage, packed);
     hipStream_t hs = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev;
     {
@@ -897,11 +989,12 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         else { PT_HIP(hipEventCreate(&ev.first)); PT_HIP(hipEventCreate(&ev.second)); }
     }
     PT_HIP(hipEventRecord(ev.first, hs));
-    if (uniform) hipLaunchKernelGGL((dev::render_kernel<false, true, true>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else if (stage && packed) hipLaunchKernelGGL((dev::render_kernel<true, true, false>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else if (stage) hipLaunchKernelGGL((dev::render_kernel<true, false, false>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else if (packed) hipLaunchKernelGGL((dev::render_kernel<false, true, false>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else hipLaunchKernelGGL((dev::render_kernel<false, false, false>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    if (walk == 1) hipLaunchKernelGGL((dev::render_kernel<false, true, 1>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (walk == 2) hipLaunchKernelGGL((dev::render_kernel<false, true, 2>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (stage && packed) hipLaunchKernelGGL((dev::render_kernel<true, true, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (stage) hipLaunchKernelGGL((dev::render_kernel<true, false, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (packed) hipLaunchKernelGGL((dev::render_kernel<false, true, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else hipLaunchKernelGGL((dev::render_kernel<false, false, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(ev.second, hs));
     {

@@ -289,7 +289,8 @@ class DevicePathTracer:
         capi.check(capi.lib().pt_set_thread_block_size(self._h, *self.threadBlockSize_))
 
     def setTraversalMode(self, mode: int):
-        """0 auto, 1 per-lane walk, 2 wave-uniform walk (small trees only)."""
+        """0 auto, 1 per-lane walk, 2 wave-uniform walk / path mask (<= 64 inner nodes),
+        3 wave-uniform walk / LDS stack (<= 4096 inner nodes)."""
         capi.check(capi.lib().pt_set_traversal_mode(self._h, mode))
 
     # -- additions: exact work counters and kernel time (the metric's inputs)

@@ -107,11 +107,11 @@ def test_closest_hit_matches_oracle_on_random_rays(pt, box_scene, duck_scene, bo
     tr.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("W,H,spp,depth", [(64, 64, 4, 4), (200, 120, 8, 8), (50, 34, 3, 1)])
 def test_cornell_box_image_bit_exact(pt, box_scene, box_oracle, gpu_device, W, H, spp, depth, mode):
-    """Both traversal schedules (1 = per-lane two-phase walk, 2 = wave-uniform walk) must give the
-    oracle's bytes AND the oracle's exact test counts."""
+    """Every traversal schedule (1 = per-lane two-phase walk, 2 / 3 = wave-uniform walks) must give
+    the oracle's bytes AND the oracle's exact test counts."""
     ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
     _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, W, H, spp, depth, mode=mode), ref)
 
@@ -122,6 +122,7 @@ def test_wave_uniform_mode_is_refused_for_big_trees(pt, duck_scene, gpu_device):
     with pytest.raises(pt.capi.PtError) as e:
         tr.setTraversalMode(2)          # 332 inner nodes > 64
     assert e.value.status == 6
+    tr.setTraversalMode(3)              # fine for the stack walk
     tr.close()
 
 
@@ -131,10 +132,11 @@ def test_cornell_box_config1_400x400_16spp_4bounce(pt, box_scene, box_oracle, gp
     _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, 400, 400, 16, 4), ref)
 
 
+@pytest.mark.parametrize("mode", [1, 3])
 @pytest.mark.parametrize("W,H,spp,depth", [(64, 36, 2, 4), (96, 54, 3, 8)])
-def test_cornell_duck_image_bit_exact(pt, duck_scene, duck_oracle, gpu_device, W, H, spp, depth):
+def test_cornell_duck_image_bit_exact(pt, duck_scene, duck_oracle, gpu_device, W, H, spp, depth, mode):
     ref = duck_oracle.render(DUCK_CAMERA, W, H, spp, depth, threads=8)
-    _assert_same(_render_gpu(pt, duck_scene, DUCK_CAMERA, W, H, spp, depth), ref)
+    _assert_same(_render_gpu(pt, duck_scene, DUCK_CAMERA, W, H, spp, depth, mode=mode), ref)
 
 
 def test_task_partition_invariance(pt, box_scene, box_oracle, gpu_device):
