@@ -161,20 +161,23 @@ def gather_frame(packed, width: int, height: int, band_rows: int, rgb_flat, yuv_
         return
     sizes = [packed_size(width, height, band_row_ranges(height, band_rows, world, r)) for r in range(world)]
     cap = max(sizes)
-    if packed.numel() == cap:
+    # RCCL ("nccl") moves device buffers directly over xGMI; with the CPU-only "gloo" backend
+    # (tests, rehearsals on one GPU) the same bytes are staged through host memory
+    xdev = packed.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    if packed.numel() == cap and packed.device == xdev:
         send = packed
     else:
-        send = torch.zeros(cap, dtype=torch.uint8, device=packed.device)
+        send = torch.zeros(cap, dtype=torch.uint8, device=xdev)
         send[:packed.numel()] = packed
-    recv = [torch.empty(cap, dtype=torch.uint8, device=packed.device) for _ in range(world)] if rank == 0 else None
+    recv = [torch.empty(cap, dtype=torch.uint8, device=xdev) for _ in range(world)] if rank == 0 else None
     dist.gather(send, recv, dst=0, group=group)
     if rank == 0:
         for r in range(1, world):          # rank 0's own bands are already in place
+            part = recv[r][:sizes[r]].to(rgb_flat.device)
             if strided:
-                unpack_bands_strided(recv[r][:sizes[r]], rgb_flat, yuv_flat, width, height, band_rows, world, r)
+                unpack_bands_strided(part, rgb_flat, yuv_flat, width, height, band_rows, world, r)
             else:
-                unpack_bands(recv[r][:sizes[r]], rgb_flat, yuv_flat, width, height,
-                             band_row_ranges(height, band_rows, world, r))
+                unpack_bands(part, rgb_flat, yuv_flat, width, height, band_row_ranges(height, band_rows, world, r))
 
 
 class RenderManager:

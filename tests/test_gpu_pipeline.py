@@ -84,6 +84,49 @@ def test_single_launch_bands_equal_whole_frame(pt, box_scene, box_oracle, gpu_de
     tr.close()
 
 
+def _rank_worker(rank, world, port, W, H, spp, depth, band, out_path):
+    import importlib
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    pt = importlib.import_module("multi-gpu-path-tracer_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # one GPU on this box: RCCL needs one per rank
+    scene = pt.SceneLoader().load(os.path.join(ROOT, "models", "cornell_box.glb")).applyCornellConvention()
+    cfg = pt.RendererConfig(samplesPerPixel=spp, recursionDepth=depth, gpuNumber=world,
+                            resolution=pt.Resolution(W, H), showTasks=False)
+    mgr = pt.RenderManager(cfg, scene, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]), device_idx=0, band_rows=band)
+    mgr.renderFrame()
+    mgr.renderFrame()                                                     # a second frame: buffers are reused
+    cnt = mgr.tracer.readCounters()
+    tot = torch.tensor([float(cnt["segments"])], dtype=torch.float64)
+    dist.all_reduce(tot)
+    if rank == 0:
+        np.savez(out_path, rgb=mgr.getCurrentFrame(), yuv=mgr.getYUVFrame(), segments=np.array([tot.item() / 2]))
+    dist.barrier()
+    mgr.reset()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H,band", [(2, 96, 64, 8), (3, 64, 36, 8)])
+def test_multi_rank_render_manager_frame_equals_oracle(box_oracle, gpu_device, tmp_path, world, W, H, band):
+    """The N > 1 path end to end on real kernels: `world` processes (all on this box's one GPU,
+    `gloo` for the exchange) each render only their row bands in ONE launch, rank 0 gathers --
+    the gathered frame must be the oracle's, and the ranks' segment counts must add up to it."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "frame.npz")
+    spp, depth = 3, 4
+    mp.spawn(_rank_worker, args=(world, port, W, H, spp, depth, band, out), nprocs=world, join=True)
+    got = np.load(out)
+    ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    assert np.array_equal(got["rgb"], ref[0]) and np.array_equal(got["yuv"], ref[1])
+    assert int(got["segments"][0]) == ref[2]["segments"]
+
+
 def _read_ppm(path):
     b = open(path, "rb").read()
     magic, dims, mx, data = b.split(b"\n", 3)
