@@ -172,3 +172,19 @@ def test_edge_cases(pt, box_scene, box_oracle, gpu_device):
     with pytest.raises(pt.capi.PtError) as e:
         pt.DevicePathTracer(0, 1, 1, (8, 8), dark, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
     assert e.value.status == 3
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+def test_synthetic_terrain_bit_exact(pt, ob, gpu_device, mode):
+    """BASELINE.json configs[3] in miniature: the deterministic terrain generator at grid 48
+    (4610 triangles, leaves of hundreds of triangles, traversal stack 10+ deep) against the oracle,
+    through both the per-lane walk (what the 8M-triangle scene uses) and the stack walk."""
+    terr = pt.make_terrain_scene(48)
+    cam = ((0.0, 220.0, 620.0), (0.0, -0.35, -1.0), 45.0, 45.0)
+    osc = ob.OracleScene(terr.triangles, terr.materials, terr.textures)
+    W, H, spp, depth = 64, 36, 2, 6
+    ref = osc.render(cam, W, H, spp, depth, threads=8)
+    assert ref[2]["max_stack"] >= 5
+    got = _render_gpu(pt, terr, cam, W, H, spp, depth, mode=mode)
+    _assert_same(got, ref)
+    assert got[0].max() > 0          # the terrain is lit
