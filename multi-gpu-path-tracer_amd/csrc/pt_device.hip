@@ -338,6 +338,7 @@ struct LdsLayout {
     const float4 *tris;
     uint32_t *stack;
     void *queue;
+    float4 *tail;             // first float4 after the traversal sections (shading tables)
 };
 
 template <bool kLds>
@@ -352,6 +353,8 @@ __device__ __forceinline__ LdsLayout lds_carve(const RenderParams &P, float4 *ba
     L.stack = reinterpret_cast<uint32_t *>(base + off);
     off += ((size_t)P.stack_entries * block + 3) / 4;
     L.queue = reinterpret_cast<void *>(base + off);
+    off += ((size_t)P.queue_entries * block * P.queue_dwords + 3) / 4;
+    L.tail = base + off;
     return L;
 }
 
@@ -374,6 +377,35 @@ __device__ __forceinline__ SceneView<kLds> stage_scene(const RenderParams &P, fl
         S.tris = reinterpret_cast<const float4 *>(P.tris);
     }
     return S;
+}
+
+// Shading tables (TriShade per slot, MatRec, LightRec).  Fetching them from HBM/L2 costs a chain
+// of three dependent loads per hit; small scenes keep them in LDS after the traversal sections.
+struct ShadeView {
+    const float4 *shade;      // 3 x float4 per slot
+    const float4 *mats;       // 3 x float4 per material
+    const float4 *lights;     // 5 x float4 per light
+};
+
+__device__ __forceinline__ ShadeView stage_shade(const RenderParams &P, float4 *lds, int tid, int block)
+{
+    ShadeView V;
+    if (P.shade_lds) {
+        const float4 *gs = reinterpret_cast<const float4 *>(P.shade);
+        const float4 *gm = reinterpret_cast<const float4 *>(P.mats);
+        const float4 *gl = reinterpret_cast<const float4 *>(P.lights);
+        const int ns = P.n_tris * 3, nm = P.n_mats * 3, nl = P.n_lights * 5;
+        for (int i = tid; i < ns; i += block) lds[i] = gs[i];
+        for (int i = tid; i < nm; i += block) lds[ns + i] = gm[i];
+        for (int i = tid; i < nl; i += block) lds[ns + nm + i] = gl[i];
+        __syncthreads();
+        V.shade = lds; V.mats = lds + ns; V.lights = lds + ns + nm;
+    } else {
+        V.shade = reinterpret_cast<const float4 *>(P.shade);
+        V.mats = reinterpret_cast<const float4 *>(P.mats);
+        V.lights = reinterpret_cast<const float4 *>(P.lights);
+    }
+    return V;
 }
 
 // render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
@@ -402,6 +434,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
     const int pixel_index = (P.H - y - 1) * P.W + x;
     const LdsLayout L = lds_carve<kLds>(P, lds_raw, kBlock);
     const SceneView<kLds> S = stage_scene<kLds>(P, lds_raw, tid, kBlock);
+    const ShadeView V = stage_shade(P, L.tail, tid, kBlock);
     typedef typename QueueEntry<kPacked>::type qentry;
     uint32_t *stack = L.stack + tid;
     qentry *queue = reinterpret_cast<qentry *>(L.queue) + tid;
@@ -442,13 +475,13 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
             continue;
         }
         // hit_record completion, triangle.h:100-108
-        float4 tc = S.tris[3 * (size_t)h.slot + 2];
-        v3 normal = mk3(tc.y, tc.z, tc.w);
+        const float4 tc = V.shade[3 * (size_t)h.slot + 2];
+        v3 normal = mk3(tc.x, tc.y, tc.z);
         v3 p = ro + h.t * rd;
-        const float4 *sp4 = reinterpret_cast<const float4 *>(P.shade + h.slot);
+        const float4 *sp4 = V.shade + 3 * (size_t)h.slot;
         float4 s0 = sp4[0], s1 = sp4[1];
         int mat = __float_as_int(s1.z);
-        const float4 *mp = reinterpret_cast<const float4 *>(P.mats + mat);
+        const float4 *mp = V.mats + 3 * (size_t)mat;
         float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
         int baseTex = __float_as_int(m0.w), emisTex = __float_as_int(m1.w);
         float tu = 0.0f, tv = 0.0f;
@@ -473,7 +506,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
         if (xorwow_uniform(rng) < 0.5f) {                              // mixture_pdf::generate, pdf.h:66-72
             float uu = xorwow_uniform(rng);                            // hitable_list::random, hitable_list.h:23-26
             int idx = (int)truncf((float)((double)uu * P.light_index_scale));
-            const float4 *lp = reinterpret_cast<const float4 *>(P.lights + idx);
+            const float4 *lp = V.lights + 5 * (size_t)idx;
             float4 la = lp[0], ld = lp[3], le = lp[4];
             float r1 = xorwow_uniform(rng), r2 = xorwow_uniform(rng);  // triangle::random, triangle.h:41-47
             float sq = sqrtf(r1);
@@ -493,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
         // hitable_list::pdf_value, hitable_list.h:16-22 -> triangle::pdf_value, triangle.h:32-40
         float lsum = 0.0f;
         for (int k = 0; k < P.n_lights; k++) {
-            const float4 *lp = reinterpret_cast<const float4 *>(P.lights + k);
+            const float4 *lp = V.lights + 5 * (size_t)k;
             float4 la = lp[0], lb = lp[1], lc = lp[2], le = lp[4];
             v3 v0 = mk3(la.x, la.y, la.z), e1 = mk3(la.w, lb.x, lb.y), e2 = mk3(lb.z, lb.w, lc.x);
             v3 ln = mk3(lc.y, lc.z, lc.w);
@@ -654,7 +687,7 @@ struct pt_device {
     // scene (host mirrors for introspection)
     RefBvh bvh;
     std::vector<int> light_faces;
-    size_t n_tris = 0, n_pairs = 0;
+    size_t n_tris = 0, n_pairs = 0, n_mats = 0;
     bool lds_scene = false;       // node + triangle arrays staged in LDS by every workgroup
     bool packed_queue = false;    // leaf-queue entries fit one dword (< 65536 triangles)
     int walk = 0;                 // traversal schedule: 0 per-lane, 1 uniform/mask, 2 uniform/stack
@@ -868,6 +901,7 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
         sh.u1 = t.v1.texCoords[0]; sh.v1 = t.v1.texCoords[1];
         sh.u2 = t.v2.texCoords[0]; sh.v2 = t.v2.texCoords[1];
         sh.material = t.materialIdx; sh.face = face;
+        sh.nx = isect[s].nx; sh.ny = isect[s].ny; sh.nz = isect[s].nz; sh.pad = 0.0f;
     }
     std::vector<LightRec> lrec(lights.size());
     for (size_t i = 0; i < lights.size(); i++) {
@@ -891,6 +925,7 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
     dev->light_faces = lights;
     dev->n_lights = (int)lights.size();
     dev->n_tris = n;
+    dev->n_mats = m;
     dev->n_pairs = pairs.size();
     // Stage the whole scene in LDS when it is small (Cornell box: 10 pairs + 36 triangles =
     // 2.4 KB); the queue holds every leaf a ray can meet when the tree is small, else 8.
@@ -948,12 +983,13 @@ pt_status pt_set_thread_block_size(pt_device *dev, unsigned x, unsigned y)
 }
 
 // Bytes of dynamic LDS for a workgroup of `block` lanes (mirrors dev::lds_carve).
-static size_t lds_bytes(const RenderParams &P, int block, bool stage, bool packed)
+static size_t lds_bytes(const RenderParams &P, int block, bool stage)
 {
     size_t f4 = 0;
     if (stage) f4 += (size_t)P.n_pairs * 4 + (size_t)P.n_tris * 3;
     f4 += ((size_t)P.stack_entries * block + 3) / 4;
-    f4 += ((size_t)P.queue_entries * block * (packed ? 1 : 2) + 3) / 4;
+    f4 += ((size_t)P.queue_entries * block * P.queue_dwords + 3) / 4;
+    if (P.shade_lds) f4 += (size_t)P.n_tris * 3 + (size_t)P.n_mats * 3 + (size_t)P.n_lights * 5;
     return f4 * 16;
 }
 
@@ -970,6 +1006,10 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.n_pairs = (int)dev->n_pairs;
     P.n_tris = (int)dev->n_tris;
     P.queue_entries = dev->queue_entries;
+    P.queue_dwords = dev->packed_queue ? 1 : 2;
+    P.n_mats = (int)dev->n_mats;
+    // shading tables in LDS when they are small (Cornell box: 1.9 KB)
+    P.shade_lds = (dev->n_tris * 48 + dev->n_mats * 48 + (size_t)dev->n_lights * 80) <= 16 * 1024 ? 1 : 0;
     return PT_OK;
 }
 
@@ -979,8 +1019,9 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     unsigned blocks = (unsigned)((tiles + dev::kWavesPerBlock - 1) / dev::kWavesPerBlock);
     const int walk = dev->walk;
     const bool stage = dev->lds_scene && walk == 0, packed = dev->packed_queue;
-    if (walk == 2) P.queue_entries = 0;
-    size_t lds = walk == 1 ? 0 : lds_bytes(P, dev::kBlock, stage, packed);
+    if (walk != 0) P.queue_entries = 0;
+    if (walk == 1) P.stack_entries = 0;
+    size_t lds = lds_bytes(P, dev::kBlock, stage);
     hipStream_t hs = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev;
     {
@@ -1270,7 +1311,8 @@ pt_status pt_kat_closest_hit(pt_device *dev, const float *org, const float *dirs
     PT_HIP(hipMemcpy(dorg, org, n * 12, hipMemcpyHostToDevice));
     PT_HIP(hipMemcpy(ddir, dirs, n * 12, hipMemcpyHostToDevice));
     unsigned blocks = (unsigned)((n + 255) / 256);
-    size_t lds = lds_bytes(P, 256, false, false);
+    P.queue_dwords = 2; P.shade_lds = 0;
+    size_t lds = lds_bytes(P, 256, false);
     hipLaunchKernelGGL(dev::kat_hit_kernel, dim3(blocks), dim3(256), lds, 0, P, dorg, ddir, dt, df, n);
     PT_HIP(hipGetLastError());
     PT_HIP(hipDeviceSynchronize());

@@ -64,11 +64,13 @@ struct TriIsect {
     float e1y, e1z, e2x, e2y;
     float e2z, nx, ny, nz;
 };
-// TriShade (32 B), leaf order: fetched once per accepted closest hit.
+// TriShade (48 B), leaf order: everything the integrator needs from the closest hit, fetched
+// once per accepted hit (normal = normalize(cross(e1,e2)), triangle.h:102, precomputed).
 struct TriShade {
     float u0, v0, u1, v1, u2, v2;
     int32_t material;
     int32_t face;                     // index in the uploaded triangle order
+    float nx, ny, nz, pad;
 };
 // LightRec (80 B), light-list order (DevicePathTracer.h:304-307).
 struct LightRec {

@@ -33,8 +33,11 @@ struct RenderParams {
     int spp;
     unsigned depth;
     int stack_entries;                // per-lane LDS stack slots (max_stack - 1)
-    int queue_entries;                // per-lane LDS leaf-queue slots (>= 2)
+    int queue_entries;                // per-lane LDS leaf-queue slots (>= 2; 0 for the wave-uniform walks)
+    int queue_dwords;                 // dwords per queue entry (1 packed, 2 otherwise)
     int n_pairs, n_tris;              // array lengths (for LDS staging)
+    int n_mats;                       // material records
+    int shade_lds;                    // 1: shade / material / light tables are staged in LDS
 };
 
 CameraBasis camera_basis(const pt_camera &cfg);
