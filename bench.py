@@ -97,6 +97,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=48)
     ap.add_argument("--ppm", default=None, help="write the gathered frame of the last step here")
+    ap.add_argument("--bvh", default=None, choices=["reference", "sah"],
+                    help="acceleration structure: the reference's topology (default; results identical to the "
+                         "reference traversal) or the opt-in SAH tree (default for c4, where the reference's tree "
+                         "makes every ray test ~730k triangles)")
     ap.add_argument("--width", type=int, default=0, help="diagnostic: override the config's width")
     ap.add_argument("--height", type=int, default=0, help="diagnostic: override the config's height")
     ap.add_argument("--share-of", type=int, default=0,
@@ -127,7 +131,12 @@ def main():
     cfg = pt.RendererConfig(samplesPerPixel=spp, recursionDepth=depth, gpuNumber=world,
                             resolution=pt.Resolution(W, H), showTasks=False)
     cam = pt.CameraConfig(camera[0], camera[1])
-    mgr = pt.RenderManager(cfg, scene, cam, device_idx=local_rank, band_rows=args.band_rows)
+    bvh = args.bvh or ("sah" if args.config == "c4" else "reference")
+    desc += " [bvh=%s]" % bvh
+    t_up = time.perf_counter()
+    mgr = pt.RenderManager(cfg, scene, cam, device_idx=local_rank, band_rows=args.band_rows,
+                           bvh_mode=1 if bvh == "sah" else 0)
+    upload_s = time.perf_counter() - t_up
 
     if args.share_of > 1 and world == 1:
         # what one rank of an N-GPU run computes, measured on this GPU alone (no gather)
@@ -197,6 +206,7 @@ def main():
                        "parallelism": "row-bands x%d (band_rows=%d), scene replicated, gather to rank 0"
                                       % (world, args.band_rows)},
             "segments_per_frame": total["segments"] // args.steps,
+            "scene_upload_s": upload_s,
             "segments_per_path": total["segments"] / max(total["paths"], 1),
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -100,6 +100,11 @@ PT_API pt_status pt_bind_framebuffer(pt_device *dev, int width, int height,
                                      uint8_t *rgb_device, uint8_t *yuv_device);
 /* setThreadBlockSize(dim3), DevicePathTracer.h:368: a hint (pixel-tile shape per wave). */
 PT_API pt_status pt_set_thread_block_size(pt_device *dev, unsigned x, unsigned y);
+/* Acceleration structure built by the NEXT pt_upload_scene: 0 = the reference's topology
+ * (bvh.h:20-176; results identical to the reference's traversal), 1 = opt-in SAH tree with
+ * distance pruning: same Moller-Trumbore arithmetic and tie-breaking, but a
+ * different set of tested triangles, so ill-conditioned rays can resolve differently.     */
+PT_API pt_status pt_set_bvh_mode(pt_device *dev, int mode);
 /* Traversal schedule of the render kernel (same results and test counts, different order of
  * work across the lanes of a wave): 0 = auto, 1 = per-lane two-phase walk (any
  * scene), 2 = wave-uniform walk with a 64-bit path mask (trees of <= 64 inner nodes),

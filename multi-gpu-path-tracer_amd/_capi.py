@@ -72,6 +72,7 @@ _PROTOS = {
     "pt_bind_framebuffer": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "pt_set_thread_block_size": (C.c_int, [_vp, C.c_uint, C.c_uint]),
     "pt_set_traversal_mode": (C.c_int, [_vp, C.c_int]),
+    "pt_set_bvh_mode": (C.c_int, [_vp, C.c_int]),
     "pt_render_task_async": (C.c_int, [_vp, C.POINTER(Task), C.POINTER(Camera), C.c_uint, C.c_uint, _vp]),
     "pt_render_bands_async": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(Camera), C.c_uint, C.c_uint, _vp]),
     "pt_stream_sync": (C.c_int, [_vp, _vp]),

@@ -168,3 +168,187 @@ void build_reference_bvh(const float *positions9, size_t n_tris, RefBvh &out)
 }
 
 } // namespace pt
+
+// ===================================================================================
+// Opt-in "SAH" acceleration structure: tight bounds, 16-bin surface-area
+// heuristic, leaves of <= 4 triangles, boxes inflated by a small epsilon so that pruning by
+// distance stays conservative with respect to the Moller-Trumbore arithmetic.  It does NOT
+// reproduce the reference's set of tested triangles (that set is defined by the reference's
+// origin-containing boxes), so results can differ from the reference in ill-conditioned cases
+// (rays grazing a triangle's plane); DESIGN.md quantifies the difference.  Ties in t are
+// resolved by `rank` (the reference's visit order when available) exactly as the reference
+// resolves them.
+// ===================================================================================
+#include <cfloat>
+#include <future>
+
+namespace pt {
+namespace {
+
+struct SahTri { float bmin[3], bmax[3], c[3]; int face; };
+
+struct SahNode {
+    float bmin[3], bmax[3];
+    int left = -1, right = -1;      // children (node ids) or -1
+    uint32_t first = 0, count = 0;  // leaf range in the ordered triangle array
+};
+
+struct SahBuilder {
+    std::vector<SahTri> &tris;
+    std::vector<SahNode> nodes;     // per-subtree pools are merged by the caller
+    explicit SahBuilder(std::vector<SahTri> &t) : tris(t) {}
+
+    static void grow(float *mn, float *mx, const float *a, const float *b)
+    {
+        for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], a[k]); mx[k] = std::max(mx[k], b[k]); }
+    }
+    static float half_area(const float *mn, const float *mx)
+    {
+        float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+        return ex * ey + ey * ez + ez * ex;
+    }
+
+    int build(uint32_t lo, uint32_t hi, int depth)
+    {
+        int id = (int)nodes.size();
+        nodes.emplace_back();
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        float cmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (uint32_t i = lo; i < hi; i++) { grow(mn, mx, tris[i].bmin, tris[i].bmax); grow(cmn, cmx, tris[i].c, tris[i].c); }
+        for (int k = 0; k < 3; k++) { nodes[id].bmin[k] = mn[k]; nodes[id].bmax[k] = mx[k]; }
+        uint32_t n = hi - lo;
+        if (n <= 4 || depth >= 60) { nodes[id].first = lo; nodes[id].count = n; return id; }
+        constexpr int kBins = 16;
+        float best = FLT_MAX;
+        int best_axis = -1, best_bin = 0;
+        for (int axis = 0; axis < 3; axis++) {
+            float ext = cmx[axis] - cmn[axis];
+            if (!(ext > 0.0f)) continue;
+            uint32_t cnt[kBins] = {0};
+            float bmn[kBins][3], bmx[kBins][3];
+            for (int b = 0; b < kBins; b++) for (int k = 0; k < 3; k++) { bmn[b][k] = FLT_MAX; bmx[b][k] = -FLT_MAX; }
+            float scale = (float)kBins / ext;
+            for (uint32_t i = lo; i < hi; i++) {
+                int b = std::min(kBins - 1, (int)((tris[i].c[axis] - cmn[axis]) * scale));
+                cnt[b]++;
+                grow(bmn[b], bmx[b], tris[i].bmin, tris[i].bmax);
+            }
+            float rarea[kBins];
+            uint32_t rcount[kBins];
+            float amn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, amx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            uint32_t acc = 0;
+            for (int b = kBins - 1; b > 0; b--) {
+                if (cnt[b]) grow(amn, amx, bmn[b], bmx[b]);
+                acc += cnt[b];
+                rarea[b] = acc ? half_area(amn, amx) : 0.0f;
+                rcount[b] = acc;
+            }
+            float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            acc = 0;
+            for (int b = 0; b < kBins - 1; b++) {
+                if (cnt[b]) grow(lmn, lmx, bmn[b], bmx[b]);
+                acc += cnt[b];
+                if (acc == 0 || rcount[b + 1] == 0) continue;
+                float cost = (float)acc * half_area(lmn, lmx) + (float)rcount[b + 1] * rarea[b + 1];
+                if (cost < best) { best = cost; best_axis = axis; best_bin = b; }
+            }
+        }
+        uint32_t mid;
+        if (best_axis < 0) {
+            mid = lo + n / 2;                                   // all centroids coincide: split by count
+        } else {
+            float ext = cmx[best_axis] - cmn[best_axis], scale = (float)kBins / ext, base = cmn[best_axis];
+            int axis = best_axis, bin = best_bin;
+            auto it = std::partition(tris.begin() + lo, tris.begin() + hi, [&](const SahTri &t) {
+                return std::min(kBins - 1, (int)((t.c[axis] - base) * scale)) <= bin;
+            });
+            mid = (uint32_t)(it - tris.begin());
+            if (mid == lo || mid == hi) mid = lo + n / 2;
+        }
+        int l = build(lo, mid, depth + 1);
+        int r = build(mid, hi, depth + 1);
+        nodes[id].left = l; nodes[id].right = r;
+        return id;
+    }
+};
+
+} // namespace
+
+void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out)
+{
+    out = SahBvh();
+    std::vector<SahTri> tris(n_tris);
+    float smn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, smx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t i = 0; i < n_tris; i++) {
+        const float *p = positions9 + 9 * i;
+        SahTri &t = tris[i];
+        for (int k = 0; k < 3; k++) {
+            t.bmin[k] = std::min(p[k], std::min(p[3 + k], p[6 + k]));
+            t.bmax[k] = std::max(p[k], std::max(p[3 + k], p[6 + k]));
+            t.c[k] = 0.5f * (t.bmin[k] + t.bmax[k]);
+            smn[k] = std::min(smn[k], t.bmin[k]); smx[k] = std::max(smx[k], t.bmax[k]);
+        }
+        t.face = (int)i;
+    }
+    SahBuilder b(tris);
+    b.nodes.reserve(n_tris);
+    int root = b.build(0, (uint32_t)n_tris, 0);
+    // epsilon: absolute part from the scene extent, relative part from the coordinate magnitude
+    float ext = std::max(smx[0] - smn[0], std::max(smx[1] - smn[1], smx[2] - smn[2]));
+    float mag = 0.0f;
+    for (int k = 0; k < 3; k++) mag = std::max(mag, std::max(fabsf(smn[k]), fabsf(smx[k])));
+    const float eps = 1e-4f * ext + 1e-5f * mag + 1e-6f;
+    // flatten inner nodes to NodePair records in DFS pre-order; a leaf root becomes a pair whose
+    // right child is an empty (inverted) box
+    std::vector<int> pair_of(b.nodes.size(), -1);
+    std::vector<int> order;
+    {
+        std::vector<int> todo{root};
+        while (!todo.empty()) {
+            int id = todo.back(); todo.pop_back();
+            if (b.nodes[id].left < 0) continue;
+            pair_of[id] = (int)order.size(); order.push_back(id);
+            todo.push_back(b.nodes[id].right); todo.push_back(b.nodes[id].left);
+        }
+    }
+    auto put_child = [&](NodePair &p, int side, int child) {
+        float *mn[3] = {side ? &p.rxmin : &p.lxmin, side ? &p.rymin : &p.lymin, side ? &p.rzmin : &p.lzmin};
+        float *mx[3] = {side ? &p.rxmax : &p.lxmax, side ? &p.rymax : &p.lymax, side ? &p.rzmax : &p.lzmax};
+        uint32_t &link = side ? p.rlink : p.llink, &cnt = side ? p.rcnt : p.lcnt;
+        if (child < 0) {                                        // empty: never hit
+            for (int k = 0; k < 3; k++) { *mn[k] = INFINITY; *mx[k] = -INFINITY; }
+            link = 0; cnt = 1;
+            return;
+        }
+        const SahNode &c = b.nodes[child];
+        for (int k = 0; k < 3; k++) { *mn[k] = c.bmin[k] - eps; *mx[k] = c.bmax[k] + eps; }
+        if (c.left < 0) { link = c.first; cnt = c.count; }
+        else { link = (uint32_t)pair_of[child]; cnt = 0; }
+    };
+    if (order.empty()) {
+        out.pairs.resize(1);
+        put_child(out.pairs[0], 0, root);
+        put_child(out.pairs[0], 1, -1);
+    } else {
+        out.pairs.resize(order.size());
+        for (size_t i = 0; i < order.size(); i++) {
+            put_child(out.pairs[i], 0, b.nodes[order[i]].left);
+            put_child(out.pairs[i], 1, b.nodes[order[i]].right);
+        }
+    }
+    out.order.resize(n_tris);
+    for (size_t i = 0; i < n_tris; i++) out.order[i] = tris[i].face;
+    // depth of the pair tree = worst-case traversal stack
+    std::vector<std::pair<uint32_t, uint32_t>> st{{0u, 1u}};
+    while (!st.empty()) {
+        auto [pi, d] = st.back(); st.pop_back();
+        out.max_stack = std::max(out.max_stack, d);
+        const NodePair &p = out.pairs[pi];
+        if (p.lcnt == 0) st.push_back({p.llink, d + 1});
+        if (p.rcnt == 0) st.push_back({p.rlink, d + 1});
+        if (p.lcnt) out.max_leaf = std::max(out.max_leaf, p.lcnt);
+        if (p.rcnt) out.max_leaf = std::max(out.max_leaf, p.rcnt);
+    }
+}
+
+} // namespace pt

@@ -69,6 +69,24 @@ __device__ __forceinline__ bool tri_hit(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float t
     return ok;
 }
 
+// Moller-Trumbore arithmetic of triangle.h:63-98 without the interval test: the u/v/t values and
+// whether det, u and v pass (same operations, same order as tri_hit).
+__device__ __forceinline__ bool mt_eval(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float &t, float &u, float &v)
+{
+    v3 pvec = cross(d, e2);
+    float det = dot(e1, pvec);
+    bool ok = !((det <= 1e-8f) & (det >= -1e-8f));
+    float inv_det = 1.0f / det;
+    v3 tvec = o - v0;
+    u = dot(tvec, pvec) * inv_det;
+    ok = ok & !((u < 0) | (u > 1));
+    v3 qvec = cross(tvec, e1);
+    v = dot(d, qvec) * inv_det;
+    ok = ok & !((v < 0) | (u + v > 1));
+    t = dot(e2, qvec) * inv_det;
+    return ok;
+}
+
 __device__ __forceinline__ void load_tri(const TriIsect *tris, int slot, v3 &v0, v3 &e1, v3 &e2)
 {
     const float4 *p = reinterpret_cast<const float4 *>(tris + slot);
@@ -294,6 +312,80 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
     return h;
 }
 
+// Opt-in walk over the SAH tree (pt_set_bvh_mode(dev, 1); not the reference's traversal): per-lane
+// LDS stack, nearer child first, subtrees whose (epsilon-inflated) box starts beyond the closest
+// hit so far are pruned.  Triangles are tested with the same Moller-Trumbore arithmetic and the
+// closest hit is min over (t, rank) -- rank = the triangle's position in the reference's visit
+// order -- which is what the reference's in-order `t < ray_t.max` update computes over the
+// triangles it tests.  Differences from the reference are confined to rays for which the two
+// traversals test different triangles AND such a triangle wins.
+__device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
+                                            uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
+{
+    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+    float tbest = tmax0;
+    uint32_t best_rank = 0xFFFFFFFFu;
+    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
+    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
+    uint32_t pair = 0;
+    int sp = 0;
+    while (true) {
+        const float4 *np = nodes + 4 * (size_t)pair;
+        const float4 a = np[0], b = np[1], c = np[2], lf = np[3];
+        const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
+        const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
+        float tnl, tnr;
+        bool hl, hr;
+        {
+            float t1 = (a.x - o.x) * inv.x, t2 = (a.y - o.x) * inv.x, t3 = (a.z - o.y) * inv.y, t4 = (a.w - o.y) * inv.y;
+            float t5 = (b.x - o.z) * inv.z, t6 = (b.y - o.z) * inv.z;
+            tnl = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+            float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+            hl = (tf >= fmaxf(tnl, 0.0f)) & (tnl <= tbest);
+        }
+        {
+            float t1 = (b.z - o.x) * inv.x, t2 = (b.w - o.x) * inv.x, t3 = (c.x - o.y) * inv.y, t4 = (c.y - o.y) * inv.y;
+            float t5 = (c.z - o.z) * inv.z, t6 = (c.w - o.z) * inv.z;
+            tnr = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+            float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+            hr = (tf >= fmaxf(tnr, 0.0f)) & (tnr <= tbest);
+        }
+        n_box += 2;
+        // leaf children: one Moller-Trumbore loop over both ranges
+        uint32_t k0 = llink, n0 = (hl && lcnt) ? lcnt : 0u;
+        uint32_t k1 = rlink, n1 = (hr && rcnt) ? rcnt : 0u;
+        if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
+        while (n0 != 0) {
+            const float4 *tp = tris + 3 * (size_t)k0;
+            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+            float t, u, v;
+            n_tri++;
+            const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d, t, u, v);
+            const uint32_t rank = __float_as_uint(tc.y);
+            if (ok & (t > tmin) & ((t < tbest) | ((t == tbest) & (rank < best_rank)))) {
+                tbest = t; best_rank = rank; h.t = t; h.u = u; h.v = v; h.slot = (int)k0;
+            }
+            k0++; n0--;
+            if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
+        }
+        const bool gl = hl && lcnt == 0 && tnl <= tbest, gr = hr && rcnt == 0 && tnr <= tbest;
+        if (gl && gr) {
+            const bool left_first = tnl <= tnr;
+            stack[sp * stride] = left_first ? rlink : llink;
+            sp++;
+            pair = left_first ? llink : rlink;
+        } else if (gl || gr) {
+            pair = gl ? llink : rlink;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            pair = stack[sp * stride];
+        }
+    }
+    return h;
+}
+
 // BaseColorTexture::value + pixel_data, Texture.h:30-69.  The reference reads row `height`
 // (one past the end) when j == 0; that row is clamped to height-1 here.
 __device__ __forceinline__ v3 tex_value(const RenderParams &P, int tex, float u, float v)
@@ -468,6 +560,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
         Hit h;
         if (kWalk == 1) h = traverse_uniform(P, ro, rd, 0.001f, 3.402823466e+38f, n_box, n_tri);
         else if (kWalk == 2) h = traverse_uniform_stack(P, ro, rd, 0.001f, 3.402823466e+38f, stack, kBlock, n_box, n_tri);
+        else if (kWalk == 3) h = traverse_sah(P, ro, rd, 0.001f, 3.402823466e+38f, stack, kBlock, n_box, n_tri);
         else h = traverse<kLds, kPacked>(S, ro, rd, 0.001f, 3.402823466e+38f, stack, queue, kBlock, P.queue_entries, n_box, n_tri);
         if (h.slot < 0) {
             col = col + mk3(0.0f, 0.0f, 0.0f) * atten;                // camera.h:78-79
@@ -621,8 +714,9 @@ __global__ void kat_hit_kernel(RenderParams P, const float *org, const float *di
     v3 o = mk3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
     v3 d = mk3(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
     uint32_t nb = 0, nt = 0;
-    Hit h = traverse<false, false>(S, o, d, 0.001f, 3.402823466e+38f, L.stack + threadIdx.x,
-                                   reinterpret_cast<uint2 *>(L.queue) + threadIdx.x, (int)blockDim.x, P.queue_entries, nb, nt);
+    Hit h = P.sah ? traverse_sah(P, o, d, 0.001f, 3.402823466e+38f, L.stack + threadIdx.x, (int)blockDim.x, nb, nt)
+                  : traverse<false, false>(S, o, d, 0.001f, 3.402823466e+38f, L.stack + threadIdx.x,
+                                           reinterpret_cast<uint2 *>(L.queue) + threadIdx.x, (int)blockDim.x, P.queue_entries, nb, nt);
     if (live) {
         t_out[i] = h.slot >= 0 ? h.t : -1.0f;
         int face = -1;
@@ -687,10 +781,12 @@ struct pt_device {
     // scene (host mirrors for introspection)
     RefBvh bvh;
     std::vector<int> light_faces;
-    size_t n_tris = 0, n_pairs = 0, n_mats = 0;
+    size_t n_tris = 0, n_pairs = 0, n_mats = 0, sah_stack = 0;
     bool lds_scene = false;       // node + triangle arrays staged in LDS by every workgroup
     bool packed_queue = false;    // leaf-queue entries fit one dword (< 65536 triangles)
-    int walk = 0;                 // traversal schedule: 0 per-lane, 1 uniform/mask, 2 uniform/stack
+    int walk = 0;                 // traversal schedule: 0 per-lane, 1 uniform/mask, 2 uniform/stack, 3 SAH tree
+    bool sah = false;             // uploaded with the opt-in SAH tree instead of the reference topology
+    int bvh_mode = 0;             // pt_set_bvh_mode: applies to the next pt_upload_scene
     int force_walk = -1;          // pt_set_traversal_mode: -1 auto, else the requested schedule
     int queue_entries = 8;        // per-lane leaf queue capacity (phase A -> phase B)
     // framebuffer binding
@@ -710,6 +806,7 @@ struct pt_device {
 static int choose_walk(const pt_device *d)
 {
     const bool mask_ok = d->n_pairs <= 64, stack_ok = d->n_pairs <= 4096;
+    if (d->sah) return 3;                     // the SAH tree has its own walk
     if (d->force_walk == 0) return 0;
     if (d->force_walk == 1) return mask_ok ? 1 : -1;
     if (d->force_walk == 2) return stack_ok ? 2 : -1;
@@ -835,10 +932,26 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
         return set_error(PT_ERR_NO_LIGHTS, "scene has no emissive face: the reference's light sampling dereferences an empty list (hitable_list.h:23-26)");
 
     // create_world, DevicePathTracer.h:134-146 -> BVH::BVH, bvh.h:20-33, on the host
+    const bool sah = dev->bvh_mode == 1;
+    // The reference tree is also built under the SAH option when that is affordable: its visit
+    // order ranks the triangles for exact-tie resolution.  (8M triangles: 17 s on one host core.)
+    const bool build_ref = !sah || n <= (size_t)1 << 20;
     RefBvh bvh;
-    build_reference_bvh(pos.data(), n, bvh);
-    if (bvh.max_stack > 64)
-        return set_error(PT_ERR_STACK, "BVH needs more than the reference's 64 traversal-stack entries (bvh.h:179)");
+    if (build_ref) {
+        build_reference_bvh(pos.data(), n, bvh);
+        if (!sah && bvh.max_stack > 64)
+            return set_error(PT_ERR_STACK, "BVH needs more than the reference's 64 traversal-stack entries (bvh.h:179)");
+    } else {
+        bvh.nodes.assign(1, RefNode());
+        bvh.nodes[0].triCount = (uint32_t)n;      // placeholder: "one leaf", never traversed
+        bvh.indices.resize(n);
+        for (size_t i = 0; i < n; i++) bvh.indices[i] = (int)i;
+    }
+    SahBvh sahbvh;
+    if (sah) {
+        build_sah_bvh(pos.data(), n, sahbvh);
+        if (sahbvh.max_stack > 64) return set_error(PT_ERR_STACK, "SAH tree deeper than 64 levels");
+    }
 
     // flatten: inner nodes -> NodePair records, triangles -> leaf order
     std::vector<uint32_t> pair_of(bvh.nodes.size(), 0xFFFFFFFFu);
@@ -878,6 +991,30 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
         for (size_t i = 0; i < bvh.nodes.size(); i++)
             if (bvh.nodes[i].triCount == 0) fill_pair(pairs[pair_of[i]], bvh.nodes[i].left, bvh.nodes[i].right);
     }
+    // rank[face] = position of the face in the reference's visit order (pairs in DFS pre-order, left
+    // leaf before right leaf, triangles in `indices` order): the order in which bvh.h:178-246 meets
+    // the triangles and therefore the tie-breaker between equal t values.
+    std::vector<uint32_t> rank(n);
+    {
+        uint32_t next = 0;
+        auto rank_leaf = [&](const RefNode &lf) { for (uint32_t k = 0; k < lf.triCount; k++) rank[(size_t)bvh.indices[lf.firstTri + k]] = next++; };
+        if (root_leaf || !build_ref) {
+            for (size_t i = 0; i < n; i++) rank[(size_t)bvh.indices[i]] = (uint32_t)i;
+        } else {
+            std::vector<uint32_t> todo{0};
+            while (!todo.empty()) {
+                uint32_t id = todo.back(); todo.pop_back();
+                const RefNode &nd = bvh.nodes[id];
+                const RefNode &l = bvh.nodes[nd.left], &r = bvh.nodes[nd.right];
+                if (l.triCount) rank_leaf(l);
+                if (r.triCount) rank_leaf(r);
+                if (r.triCount == 0) todo.push_back(nd.right);
+                if (l.triCount == 0) todo.push_back(nd.left);
+            }
+        }
+    }
+    if (sah) pairs = sahbvh.pairs;
+    const std::vector<int> &slot_face = sah ? sahbvh.order : bvh.indices;
     std::vector<TriIsect> isect(n);
     std::vector<TriShade> shade(n);
     auto make_isect = [&](const pt_triangle &t, float *out12, float *area, float *v1v2) {
@@ -893,7 +1030,7 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
         if (v1v2) { v1v2[0] = v1.x; v1v2[1] = v1.y; v1v2[2] = v1.z; v1v2[3] = v2.x; v1v2[4] = v2.y; v1v2[5] = v2.z; }
     };
     for (size_t s = 0; s < n; s++) {
-        int face = bvh.indices[s];
+        int face = slot_face[s];
         const pt_triangle &t = tris[face];
         make_isect(t, &isect[s].v0x, nullptr, nullptr);
         TriShade &sh = shade[s];
@@ -902,6 +1039,7 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
         sh.u2 = t.v2.texCoords[0]; sh.v2 = t.v2.texCoords[1];
         sh.material = t.materialIdx; sh.face = face;
         sh.nx = isect[s].nx; sh.ny = isect[s].ny; sh.nz = isect[s].nz; sh.pad = 0.0f;
+        memcpy(&isect[s].nx, &rank[(size_t)face], 4);       // traversal-side record carries the rank instead
     }
     std::vector<LightRec> lrec(lights.size());
     for (size_t i = 0; i < lights.size(); i++) {
@@ -932,6 +1070,8 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
     const size_t scene_bytes = pairs.size() * sizeof(NodePair) + n * sizeof(TriIsect);
     dev->lds_scene = scene_bytes <= 24 * 1024;
     dev->packed_queue = n < 65536;
+    dev->sah = sah;
+    dev->sah_stack = sah ? sahbvh.max_stack : 0;
     dev->walk = choose_walk(dev);
     dev->queue_entries = (int)std::min<uint32_t>(std::max<uint32_t>(dev->bvh.leaves + 1, 4), 12);
     dev->has_scene = true;
@@ -954,6 +1094,14 @@ pt_status pt_bind_framebuffer(pt_device *dev, int width, int height, uint8_t *rg
     if ((width | height) & 1)
         return set_error(PT_ERR_UNSUPPORTED, "odd framebuffer sizes: the reference's YUV420 indexing (DevicePathTracer.h:107-119) writes past its planes; only even widths and heights are accepted");
     dev->W = width; dev->H = height; dev->rgb = rgb; dev->yuv = yuv;
+    return PT_OK;
+}
+
+pt_status pt_set_bvh_mode(pt_device *dev, int mode)
+{
+    clear_error();
+    if (!dev || mode < 0 || mode > 1) return set_error(PT_ERR_INVALID, "bvh mode must be 0 (reference topology) or 1 (SAH tree)");
+    dev->bvh_mode = mode;
     return PT_OK;
 }
 
@@ -1006,6 +1154,8 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.n_pairs = (int)dev->n_pairs;
     P.n_tris = (int)dev->n_tris;
     P.queue_entries = dev->queue_entries;
+    P.sah = dev->sah ? 1 : 0;
+    if (dev->sah) P.stack_entries = (int)dev->sah_stack;
     P.queue_dwords = dev->packed_queue ? 1 : 2;
     P.n_mats = (int)dev->n_mats;
     // shading tables in LDS when they are small (Cornell box: 1.9 KB)
@@ -1030,7 +1180,8 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         else { PT_HIP(hipEventCreate(&ev.first)); PT_HIP(hipEventCreate(&ev.second)); }
     }
     PT_HIP(hipEventRecord(ev.first, hs));
-    if (walk == 1) hipLaunchKernelGGL((dev::render_kernel<false, true, 1>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    if (walk == 3) hipLaunchKernelGGL((dev::render_kernel<false, true, 3>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (walk == 1) hipLaunchKernelGGL((dev::render_kernel<false, true, 1>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (walk == 2) hipLaunchKernelGGL((dev::render_kernel<false, true, 2>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (stage && packed) hipLaunchKernelGGL((dev::render_kernel<true, true, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (stage) hipLaunchKernelGGL((dev::render_kernel<true, false, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);

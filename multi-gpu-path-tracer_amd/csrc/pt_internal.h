@@ -86,6 +86,15 @@ struct MatRec {
     float er, eg, eb; int32_t emisTex;          // emissiveFactor_, emissiveTexture_
     float e50r, e50g, e50b; int32_t is_light;   // emissiveFactor_*50 (material.h:85)
 };
+// Opt-in SAH tree (pt_bvh.cpp): NodePair records in DFS pre-order, leaves of <= 4 triangles,
+// `order[slot]` = face index of the triangle stored at leaf-order slot `slot`.
+struct SahBvh {
+    std::vector<NodePair> pairs;
+    std::vector<int> order;
+    uint32_t max_stack = 0, max_leaf = 0;
+};
+void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out);
+
 struct TexDesc { int32_t w, h; uint32_t offset /* in floats */, pad; };
 
 } // namespace pt

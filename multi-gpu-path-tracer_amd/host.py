@@ -288,6 +288,12 @@ class DevicePathTracer:
         self.threadBlockSize_ = tuple(threadBlockSize)
         capi.check(capi.lib().pt_set_thread_block_size(self._h, *self.threadBlockSize_))
 
+    def setBvhMode(self, mode: int, reload: bool = True):
+        """0 = reference-topology BVH (default), 1 = opt-in SAH tree; takes effect at reloadWorld()."""
+        capi.check(capi.lib().pt_set_bvh_mode(self._h, mode))
+        if reload:
+            self.reloadWorld()
+
     def setTraversalMode(self, mode: int):
         """0 auto, 1 per-lane walk, 2 wave-uniform walk / path mask (<= 64 inner nodes),
         3 wave-uniform walk / LDS stack (<= 4096 inner nodes)."""

@@ -190,7 +190,8 @@ class RenderManager:
     """
 
     def __init__(self, config: RendererConfig, hScene: HostScene, cameraConfig: CameraConfig,
-                 device_idx: int = 0, band_rows: int = 8, streams_per_gpu: Optional[int] = None):
+                 device_idx: int = 0, band_rows: int = 8, streams_per_gpu: Optional[int] = None,
+                 bvh_mode: int = 0):
         import torch
         import torch.distributed as dist
         self._torch = torch
@@ -204,6 +205,8 @@ class RenderManager:
         self.framebuffer_ = Framebuffer(config.resolution, device="cuda:%d" % device_idx)
         self.tracer = DevicePathTracer(device_idx, config.samplesPerPixel, config.recursionDepth,
                                        config.threadBlockSize, hScene, self.framebuffer_, cameraConfig)
+        if bvh_mode:
+            self.tracer.setBvhMode(bvh_mode)        # opt-in SAH tree (not the reference's traversal)
         n_streams = streams_per_gpu or config.streamsPerGpu
         self.streams = [torch.cuda.Stream(device=device_idx) for _ in range(max(1, n_streams))]
         self._make_tasks()
