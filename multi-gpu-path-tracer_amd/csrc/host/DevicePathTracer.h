@@ -98,6 +98,9 @@ public:
         checkPtErrors(pt_set_thread_block_size(dev_, threadBlockSize_.x, threadBlockSize_.y));
     }
 
+    // opt-in SAH tree instead of the reference's topology (include/pt_amd.h: pt_set_bvh_mode)
+    void setBvhMode(int mode) { checkPtErrors(pt_set_bvh_mode(dev_, mode)); reloadWorld(); }
+
     pt_stream createStream() { pt_stream s = nullptr; checkPtErrors(pt_stream_create(dev_, &s)); return s; }
     void destroyStream(pt_stream s) { checkPtErrors(pt_stream_destroy(dev_, s)); }
     pt_counters readCounters() { pt_counters c{}; checkPtErrors(pt_counters_read(dev_, &c)); return c; }

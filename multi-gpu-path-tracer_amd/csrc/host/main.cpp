@@ -23,7 +23,7 @@ int main(int argc, char **argv)
     CameraConfig cameraConfig(Float3{0, 0, 0.5f}, Float3{0, 0, -0.5f});      // main.cu:40
     std::string out = "out.ppm", yuvOut;
     int frames = 1;
-    bool cornell = false;
+    bool cornell = false, sah = false;
     for (int i = 3; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -38,6 +38,7 @@ int main(int argc, char **argv)
         else if (a == "--out") out = next();
         else if (a == "--yuv") yuvOut = next();
         else if (a == "--cornell") cornell = true;
+        else if (a == "--bvh") sah = std::string(next()) == "sah";
         else if (a == "--show-tasks") config.showTasks = true;
         else if (a == "--vfov") cameraConfig.vfov = (float)atof(next());
         else if (a == "--hfov") cameraConfig.hfov = (float)atof(next());
@@ -65,6 +66,7 @@ int main(int argc, char **argv)
     auto t1 = std::chrono::high_resolution_clock::now();
     std::cout << "initializing in: " << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << "ms" << std::endl;
 
+    if (sah) for (auto &dpt : manager.tracers()) dpt->setBvhMode(1);
     for (int f = 0; f < frames; f++) {
         for (auto &dpt : manager.tracers()) dpt->resetCounters();
         auto start = std::chrono::high_resolution_clock::now();

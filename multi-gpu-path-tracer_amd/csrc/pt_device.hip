@@ -1192,6 +1192,22 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     {
         std::lock_guard<std::mutex> lk(dev->mu);
         dev->pending.push_back(ev);
+        // keep the event pool bounded when nobody reads the timings: fold finished launches in
+        if (dev->pending.size() > 64) {
+            size_t kept = 0;
+            for (auto &pr : dev->pending) {
+                float ms = 0.0f;
+                if (hipEventQuery(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                    dev->ms_total += (double)ms;
+                    dev->launches++;
+                    dev->free_events.push_back(pr);
+                } else {
+                    dev->pending[kept++] = pr;
+                }
+            }
+            dev->pending.resize(kept);
+            (void)hipGetLastError();      // hipEventQuery reports "not ready" through the error state
+        }
     }
     return PT_OK;
 }
