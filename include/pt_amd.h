@@ -132,6 +132,10 @@ PT_API pt_status pt_stream_destroy(pt_device *dev, pt_stream stream);
 /* Work counters (new; the metric's numerator).  Read after a sync. */
 PT_API pt_status pt_counters_read(pt_device *dev, pt_counters *out);
 PT_API pt_status pt_counters_reset(pt_device *dev);
+/* All 8 raw counter words: [0..4] as pt_counters; [5..7] are only written by the diagnostic
+ * PT_STAMPS build (tools/stamps.sh): longest wave lifetime, summed traversal cycles, summed
+ * wave lifetimes, in shader-clock cycles.                                                */
+PT_API pt_status pt_debug_counters_read(pt_device *dev, uint64_t out8[8]);
 /* Accumulated device time (ms) of the render kernel launches since the last reset,
  * measured with HIP events on the launch stream; n_launches may be NULL.                */
 PT_API pt_status pt_kernel_time_read(pt_device *dev, double *ms_total, uint64_t *n_launches);

@@ -81,6 +81,7 @@ _PROTOS = {
     "pt_stream_destroy": (C.c_int, [_vp, _vp]),
     "pt_counters_read": (C.c_int, [_vp, C.POINTER(Counters)]),
     "pt_counters_reset": (C.c_int, [_vp]),
+    "pt_debug_counters_read": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "pt_kernel_time_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "pt_kernel_time_reset": (C.c_int, [_vp]),
     "pt_bvh_info_read": (C.c_int, [_vp, C.POINTER(BvhInfo)]),

@@ -541,6 +541,12 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
     unsigned bounce = 0;
     bool need_new = true;
     bool alive = in_frame && P.depth > 0;     // depth 0: ray_color returns (0,0,0) untraced
+#ifdef PT_STAMPS
+    // diagnostic build only (tools/stamps.sh): shader-clock cycles spent inside the traversal vs the
+    // whole wave loop, summed per wave into counters[5..7]; never compiled into the shipped library
+    unsigned long long stamp_trav = 0, stamp_trips = 0;
+    const unsigned long long stamp_begin = __builtin_amdgcn_s_memtime();
+#endif
 
     while (alive) {
         if (need_new) {
@@ -557,11 +563,18 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
             need_new = false;
         }
         n_seg++;
+#ifdef PT_STAMPS
+        const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
         Hit h;
         if (kWalk == 1) h = traverse_uniform(P, ro, rd, 0.001f, 3.402823466e+38f, n_box, n_tri);
         else if (kWalk == 2) h = traverse_uniform_stack(P, ro, rd, 0.001f, 3.402823466e+38f, stack, kBlock, n_box, n_tri);
         else if (kWalk == 3) h = traverse_sah(P, ro, rd, 0.001f, 3.402823466e+38f, stack, kBlock, n_box, n_tri);
         else h = traverse<kLds, kPacked>(S, ro, rd, 0.001f, 3.402823466e+38f, stack, queue, kBlock, P.queue_entries, n_box, n_tri);
+#ifdef PT_STAMPS
+        stamp_trav += __builtin_amdgcn_s_memtime() - st0;
+        stamp_trips++;
+#endif
         if (h.slot < 0) {
             col = col + mk3(0.0f, 0.0f, 0.0f) * atten;                // camera.h:78-79
             need_new = true;
@@ -665,6 +678,22 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
             P.yuv[total + uvSize + uvIndex] = (uint8_t)(((112 * cr - 94 * cg - 18 * cb + 128) >> 8) + 128);
         }
     }
+#ifdef PT_STAMPS
+    {
+        const unsigned long long total = __builtin_amdgcn_s_memtime() - stamp_begin;
+        // the wave's trip count / traversal cycles = those of its longest-living lane
+        unsigned long long tr = stamp_trips, tv = stamp_trav;
+        for (int off = 32; off > 0; off >>= 1) {
+            unsigned long long o1 = __shfl_xor(tr, off, 64), o2 = __shfl_xor(tv, off, 64);
+            if (o1 > tr) { tr = o1; tv = o2; }
+        }
+        if (lane == 0) {
+            atomicMax(&P.counters[5], total);            // longest wave (cycles)
+            atomicAdd(&P.counters[6], tv);               // sum over waves: traversal cycles of the longest lane
+            atomicAdd(&P.counters[7], total);            // sum over waves: wave lifetime
+        }
+    }
+#endif
     // exact work counters: one atomic per wave per counter
     uint32_t c0 = wave_sum(n_paths), c1 = wave_sum(n_seg), c2 = wave_sum(n_box), c3 = wave_sum(n_tri),
              c4 = wave_sum(n_light);
@@ -1309,6 +1338,15 @@ pt_status pt_counters_read(pt_device *dev, pt_counters *out)
     unsigned long long h[8];
     PT_HIP(hipMemcpy(h, dev->d_counters, sizeof h, hipMemcpyDeviceToHost));
     out->paths = h[0]; out->segments = h[1]; out->box_tests = h[2]; out->tri_tests = h[3]; out->light_tests = h[4];
+    return PT_OK;
+}
+
+pt_status pt_debug_counters_read(pt_device *dev, uint64_t out8[8])
+{
+    clear_error();
+    if (!dev || !out8) return set_error(PT_ERR_INVALID, "null argument");
+    PT_HIP(hipSetDevice(dev->index));
+    PT_HIP(hipMemcpy(out8, dev->d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

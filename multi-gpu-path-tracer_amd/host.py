@@ -305,6 +305,12 @@ class DevicePathTracer:
         capi.check(capi.lib().pt_counters_read(self._h, C.byref(c)))
         return c.as_dict()
 
+    def readStamps(self):
+        """Raw counter words 5..7 (diagnostic PT_STAMPS build only)."""
+        raw = (C.c_uint64 * 8)()
+        capi.check(capi.lib().pt_debug_counters_read(self._h, raw))
+        return {"longest_wave_cycles": int(raw[5]), "sum_traversal_cycles": int(raw[6]), "sum_wave_cycles": int(raw[7])}
+
     def resetCounters(self):
         capi.check(capi.lib().pt_counters_reset(self._h))
 
