@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=48)
+    ap.add_argument("--cpu-rows", type=int, default=360)
     ap.add_argument("--ppm", default=None, help="write the gathered frame of the last step here")
     ap.add_argument("--bvh", default=None, choices=["reference", "sah"],
                     help="acceleration structure: the reference's topology (default; results identical to the "
