@@ -502,44 +502,211 @@ __device__ __forceinline__ ShadeView stage_shade(const RenderParams &P, float4 *
 
 // render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
 // camera::ray_color (camera.h:49-83) flattened into a per-lane state machine.
-// kWalk: 0 = per-lane two-phase walk, 1 = wave-uniform walk with a 64-bit path mask (<= 64 inner
-// nodes), 2 = wave-uniform walk with the per-lane LDS stack (medium trees).
-template <bool kLds, bool kPacked, int kWalk>
-__global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
+// Per-lane integrator state of camera::ray_color (camera.h:49-83) and of render's sample loop
+// (DevicePathTracer.h:80-87), plus this lane's exact work counters.
+struct PathState {
+    xorwow rng;
+    v3 col, atten, ro, rd;
+    int s;                 // samples started
+    unsigned bounce;       // segments traced on the current path
+    bool need_new;         // the next trip starts a new sample
+    uint32_t n_paths, n_seg, n_box, n_tri, n_light;
+};
+
+__device__ __forceinline__ void path_init(PathState &L, const RenderParams &P, int pixel_index)
 {
-    extern __shared__ float4 lds_raw[];
-    const int tid = threadIdx.x;
+    xorwow_init(L.rng, (uint64_t)(long long)(1984 + pixel_index));   // :54 seed, :80 state copy
+    L.col = mk3(0.0f, 0.0f, 0.0f);
+    L.atten = mk3(1.0f, 1.0f, 1.0f);
+    L.ro = P.cam.origin; L.rd = mk3(0.0f, 0.0f, 0.0f);
+    L.s = 0; L.bounce = 0; L.need_new = true;
+    L.n_paths = L.n_seg = L.n_box = L.n_tri = L.n_light = 0;
+}
+
+// Starts the next sample of pixel (x, y): DevicePathTracer.h:84-86 + camera::get_ray camera.h:95-97.
+// Returns false when all samples are done.
+__device__ __forceinline__ bool start_path(PathState &L, const RenderParams &P, int x, int y)
+{
+    if (L.s >= P.spp) return false;
+    float u = ((float)x + xorwow_uniform(L.rng)) / (float)(unsigned)P.W;
+    float v = ((float)y + xorwow_uniform(L.rng)) / (float)(unsigned)P.H;
+    L.ro = P.cam.origin;
+    L.rd = ((P.cam.llc + u * P.cam.horizontal) + v * P.cam.vertical) - P.cam.origin;
+    L.atten = mk3(1.0f, 1.0f, 1.0f);
+    L.bounce = 0;
+    L.s++;
+    L.n_paths++;
+    L.need_new = false;
+    return true;
+}
+
+// What camera::ray_color does with the result of one BVH::hit (camera.h:55-80): miss, emissive
+// hit, or a scattering bounce that sets up the next ray segment.
+__device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const ShadeView &V, const Hit &h)
+{
+    if (h.slot < 0) {
+        L.col = L.col + mk3(0.0f, 0.0f, 0.0f) * L.atten;                // camera.h:78-79
+        L.need_new = true;
+        return;
+    }
+    // hit_record completion, triangle.h:100-108
+    const float4 tc = V.shade[3 * (size_t)h.slot + 2];
+    v3 normal = mk3(tc.x, tc.y, tc.z);
+    v3 p = L.ro + h.t * L.rd;
+    const float4 *sp4 = V.shade + 3 * (size_t)h.slot;
+    float4 s0 = sp4[0], s1 = sp4[1];
+    int mat = __float_as_int(s1.z);
+    const float4 *mp = V.mats + 3 * (size_t)mat;
+    float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+    int baseTex = __float_as_int(m0.w), emisTex = __float_as_int(m1.w);
+    float tu = 0.0f, tv = 0.0f;
+    if (baseTex >= 0 || emisTex >= 0) {
+        tu = (1 - h.u - h.v) * s0.x + h.u * s0.z + h.v * s1.x;
+        tv = (1 - h.u - h.v) * s0.y + h.u * s0.w + h.v * s1.y;
+    }
+    // UniversalMaterial::emitted, material.h:80-86
+    v3 emitted = mk3(m2.x, m2.y, m2.z);
+    if (emisTex >= 0) emitted = (tex_value(P, emisTex, tu, tv) * mk3(m1.x, m1.y, m1.z)) * 50.0f;
+    if (emitted.x > 0.0001f || emitted.y > 0.0001f || emitted.z > 0.0001f) {   // material.h:63
+        L.col = L.col + L.atten * emitted;                               // camera.h:72-74
+        L.need_new = true;
+        return;
+    }
+    // material.h:67-68: a cosine sample that camera.h:65 overwrites; its 2 draws remain.
+    (void)xorwow_next(L.rng); (void)xorwow_next(L.rng);
+    v3 albedo = mk3(m0.x, m0.y, m0.z);
+    if (baseTex >= 0) albedo = albedo * tex_value(P, baseTex, tu, tv);
+    Onb uvw = onb_make(normal);                                    // cosine_pdf ctor, pdf.h:15-17
+    v3 dir;
+    if (xorwow_uniform(L.rng) < 0.5f) {                              // mixture_pdf::generate, pdf.h:66-72
+        float uu = xorwow_uniform(L.rng);                            // hitable_list::random, hitable_list.h:23-26
+        int idx = (int)truncf((float)((double)uu * P.light_index_scale));
+        const float4 *lp = V.lights + 5 * (size_t)idx;
+        float4 la = lp[0], ld = lp[3], le = lp[4];
+        float r1 = xorwow_uniform(L.rng), r2 = xorwow_uniform(L.rng);  // triangle::random, triangle.h:41-47
+        float sq = sqrtf(r1);
+        v3 lv0 = mk3(la.x, la.y, la.z), lv1 = mk3(ld.x, ld.y, ld.z), lv2 = mk3(ld.w, le.x, le.y);
+        v3 rp = ((1 - sq) * lv0 + (sq * (1 - r2)) * lv1) + (sq * r2) * lv2;
+        dir = rp - p;
+    } else {
+        float r1 = xorwow_uniform(L.rng), r2 = xorwow_uniform(L.rng);  // random_cosine_direction, helper_math.h:1519-1527
+        float z = sqrtf(1 - r2);
+        float phi = (float)(2 * M_PI * (double)r1);
+        float sn, cs;
+        pt_sincosf(phi, sn, cs);
+        float sq2 = sqrtf(r2);
+        float lx = cs * 2 * sq2, ly = sn * 2 * sq2;
+        dir = (lx * uvw.a0 + ly * uvw.a1) + z * uvw.a2;            // onb::local, onb.h:20-22
+    }
+    // hitable_list::pdf_value, hitable_list.h:16-22 -> triangle::pdf_value, triangle.h:32-40
+    float lsum = 0.0f;
+    for (int k = 0; k < P.n_lights; k++) {
+        const float4 *lp = V.lights + 5 * (size_t)k;
+        float4 la = lp[0], lb = lp[1], lc = lp[2], le = lp[4];
+        v3 v0 = mk3(la.x, la.y, la.z), e1 = mk3(la.w, lb.x, lb.y), e2 = mk3(lb.z, lb.w, lc.x);
+        v3 ln = mk3(lc.y, lc.z, lc.w);
+        float t, u, v;
+        L.n_light++;
+        float pdfv = 0.0f;
+        if (tri_hit(v0, e1, e2, p, dir, 0.001f, 3.402823466e+38f, t, u, v)) {
+            float distance_squared = t * t * dot(dir, dir);
+            float cosine = fabsf(dot(dir, ln) / length(dir));
+            pdfv = distance_squared / (cosine * le.z);
+        }
+        lsum += P.light_weight * pdfv;
+    }
+    v3 ndir = normalize(dir);
+    float cosv = dot(ndir, uvw.a2);                                // cosine_pdf::value, pdf.h:19-22
+    float cpdf = (cosv <= 0) ? 0.0f : (float)((double)cosv / M_PI);
+    float pdf_value = 0.5f * lsum + 0.5f * cpdf;                   // mixture_pdf::value, pdf.h:63-65
+    float cos2 = dot(normal, ndir);                                // scattering_pdf, material.h:88-91
+    float spdf = cos2 < 0 ? 0.0f : (float)((double)cos2 / M_PI);
+    L.atten = L.atten * ((albedo * spdf) / pdf_value);                 // camera.h:69
+    L.ro = p; L.rd = dir;
+    L.bounce++;
+    if (L.bounce >= P.depth) {
+        L.col = L.col + mk3(0.0f, 0.0f, 0.0f);                         // camera.h:82
+        L.need_new = true;
+    }
+}
+
+// Quantisation + RGB / YUV420 store of one pixel, DevicePathTracer.h:98-119.
+__device__ __forceinline__ void write_pixel(const RenderParams &P, v3 col, int pixel_index)
+{
+{
+    // :98-119
+    v3 q = (255.99f * col) / (float)P.spp;
+    int cr = f2i_rz_sat(q.x * 1.0f), cg = f2i_rz_sat(q.y * 1.0f), cb = f2i_rz_sat(q.z * 1.0f);
+    cr = min(255, cr); cg = min(255, cg); cb = min(255, cb);
+    P.rgb[3 * (size_t)pixel_index] = (uint8_t)cr;
+    P.rgb[3 * (size_t)pixel_index + 1] = (uint8_t)cg;
+    P.rgb[3 * (size_t)pixel_index + 2] = (uint8_t)cb;
+    P.yuv[pixel_index] = (uint8_t)(((66 * cr + 129 * cg + 25 * cb + 128) >> 8) + 16);
+    int blockRow = pixel_index / P.W, blockCol = pixel_index % P.W;
+    if (blockRow % 2 == 0 && blockCol % 2 == 0) {
+        int total = P.W * P.H, uvSize = total / 4;
+        int uvIndex = (blockRow / 2) * (P.W / 2) + (blockCol / 2);
+        P.yuv[total + uvIndex] = (uint8_t)(((-38 * cr - 74 * cg + 112 * cb + 128) >> 8) + 128);
+        P.yuv[total + uvSize + uvIndex] = (uint8_t)(((112 * cr - 94 * cg - 18 * cb + 128) >> 8) + 128);
+    }
+}
+}
+
+// Exact work counters: one atomic per wave per counter.
+__device__ __forceinline__ void flush_counters(const RenderParams &P, const PathState &L, int lane)
+{
+    uint32_t c0 = wave_sum(L.n_paths), c1 = wave_sum(L.n_seg), c2 = wave_sum(L.n_box), c3 = wave_sum(L.n_tri),
+             c4 = wave_sum(L.n_light);
+    if (lane == 0 && (c0 | c1)) {
+        atomicAdd(&P.counters[0], (unsigned long long)c0);
+        atomicAdd(&P.counters[1], (unsigned long long)c1);
+        atomicAdd(&P.counters[2], (unsigned long long)c2);
+        atomicAdd(&P.counters[3], (unsigned long long)c3);
+        atomicAdd(&P.counters[4], (unsigned long long)c4);
+    }
+}
+
+// Pixel of this lane: 8x8 tile per wave; in row-band mode (pt_render_bands_async) local row j is row
+// (j % band_rows) of this rank's (j / band_rows)-th band, band b of the frame (fb rows, 0 = top)
+// belonging to rank b % band_ranks.
+__device__ __forceinline__ bool lane_pixel(const RenderParams &P, int tid, int &x, int &y, int &pixel_index)
+{
     const int lane = tid & (kWave - 1);
     const int wave = tid / kWave;
     const int tile = blockIdx.x * kWavesPerBlock + wave;
     const int tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
     const int i = tile_x * 8 + (lane & 7), j = tile_y * 8 + (lane >> 3);
     const bool in_task = (tile_y < P.tiles_y) && (i < P.task_w) && (j < P.task_h);
-    int x = P.task_ox + i, y = P.task_oy + j;
+    x = P.task_ox + i; y = P.task_oy + j;
     if (P.band_ranks > 0) {
-        // row-band mode (pt_render_bands_async): local row j is row (j % band_rows) of this rank's
-        // (j / band_rows)-th band; band b of the frame (fb rows, 0 = top) belongs to rank b % band_ranks
         const int fb_row = ((j / P.band_rows) * P.band_ranks + P.band_rank) * P.band_rows + (j % P.band_rows);
         y = P.H - 1 - fb_row;
     }
-    const bool in_frame = in_task && x >= 0 && y >= 0 && x < P.W && y < P.H;
-    const int pixel_index = (P.H - y - 1) * P.W + x;
-    const LdsLayout L = lds_carve<kLds>(P, lds_raw, kBlock);
-    const SceneView<kLds> S = stage_scene<kLds>(P, lds_raw, tid, kBlock);
-    const ShadeView V = stage_shade(P, L.tail, tid, kBlock);
-    typedef typename QueueEntry<kPacked>::type qentry;
-    uint32_t *stack = L.stack + tid;
-    qentry *queue = reinterpret_cast<qentry *>(L.queue) + tid;
+    pixel_index = (P.H - y - 1) * P.W + x;
+    return in_task && x >= 0 && y >= 0 && x < P.W && y < P.H;
+}
 
-    xorwow rng;
-    xorwow_init(rng, (uint64_t)(long long)(1984 + pixel_index));     // :54 seed, :80 state copy
-    v3 col = mk3(0.0f, 0.0f, 0.0f);
-    v3 atten = mk3(1.0f, 1.0f, 1.0f);
-    v3 ro = P.cam.origin, rd = mk3(0.0f, 0.0f, 0.0f);
-    uint32_t n_paths = 0, n_seg = 0, n_box = 0, n_tri = 0, n_light = 0;
-    int s = 0;
-    unsigned bounce = 0;
-    bool need_new = true;
+// kWalk: 0 = per-lane two-phase walk, 1 = wave-uniform walk with a 64-bit path mask (<= 64 inner
+// nodes), 2 = wave-uniform walk with the per-lane LDS stack (medium trees), 3 = SAH tree walk.
+// render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
+// camera::ray_color (camera.h:49-83) flattened into a per-lane state machine.
+template <bool kLds, bool kPacked, int kWalk>
+__global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
+{
+    extern __shared__ float4 lds_raw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    int x, y, pixel_index;
+    const bool in_frame = lane_pixel(P, tid, x, y, pixel_index);
+    const LdsLayout LL = lds_carve<kLds>(P, lds_raw, kBlock);
+    const SceneView<kLds> S = stage_scene<kLds>(P, lds_raw, tid, kBlock);
+    const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
+    typedef typename QueueEntry<kPacked>::type qentry;
+    uint32_t *stack = LL.stack + tid;
+    qentry *queue = reinterpret_cast<qentry *>(LL.queue) + tid;
+
+    PathState L;
+    path_init(L, P, pixel_index);
     bool alive = in_frame && P.depth > 0;     // depth 0: ray_color returns (0,0,0) untraced
 #ifdef PT_STAMPS
     // diagnostic build only (tools/stamps.sh): shader-clock cycles spent inside the traversal vs the
@@ -549,135 +716,24 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
 #endif
 
     while (alive) {
-        if (need_new) {
-            if (s >= P.spp) { alive = false; continue; }
-            // :84-86 + camera::get_ray camera.h:95-97
-            float u = ((float)x + xorwow_uniform(rng)) / (float)(unsigned)P.W;
-            float v = ((float)y + xorwow_uniform(rng)) / (float)(unsigned)P.H;
-            ro = P.cam.origin;
-            rd = ((P.cam.llc + u * P.cam.horizontal) + v * P.cam.vertical) - P.cam.origin;
-            atten = mk3(1.0f, 1.0f, 1.0f);
-            bounce = 0;
-            s++;
-            n_paths++;
-            need_new = false;
-        }
-        n_seg++;
+        if (L.need_new && !start_path(L, P, x, y)) { alive = false; continue; }
+        L.n_seg++;
 #ifdef PT_STAMPS
         const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
         Hit h;
-        if (kWalk == 1) h = traverse_uniform(P, ro, rd, 0.001f, 3.402823466e+38f, n_box, n_tri);
-        else if (kWalk == 2) h = traverse_uniform_stack(P, ro, rd, 0.001f, 3.402823466e+38f, stack, kBlock, n_box, n_tri);
-        else if (kWalk == 3) h = traverse_sah(P, ro, rd, 0.001f, 3.402823466e+38f, stack, kBlock, n_box, n_tri);
-        else h = traverse<kLds, kPacked>(S, ro, rd, 0.001f, 3.402823466e+38f, stack, queue, kBlock, P.queue_entries, n_box, n_tri);
+        if (kWalk == 1) h = traverse_uniform(P, L.ro, L.rd, 0.001f, 3.402823466e+38f, L.n_box, L.n_tri);
+        else if (kWalk == 2) h = traverse_uniform_stack(P, L.ro, L.rd, 0.001f, 3.402823466e+38f, stack, kBlock, L.n_box, L.n_tri);
+        else if (kWalk == 3) h = traverse_sah(P, L.ro, L.rd, 0.001f, 3.402823466e+38f, stack, kBlock, L.n_box, L.n_tri);
+        else h = traverse<kLds, kPacked>(S, L.ro, L.rd, 0.001f, 3.402823466e+38f, stack, queue, kBlock, P.queue_entries, L.n_box, L.n_tri);
 #ifdef PT_STAMPS
         stamp_trav += __builtin_amdgcn_s_memtime() - st0;
         stamp_trips++;
 #endif
-        if (h.slot < 0) {
-            col = col + mk3(0.0f, 0.0f, 0.0f) * atten;                // camera.h:78-79
-            need_new = true;
-            continue;
-        }
-        // hit_record completion, triangle.h:100-108
-        const float4 tc = V.shade[3 * (size_t)h.slot + 2];
-        v3 normal = mk3(tc.x, tc.y, tc.z);
-        v3 p = ro + h.t * rd;
-        const float4 *sp4 = V.shade + 3 * (size_t)h.slot;
-        float4 s0 = sp4[0], s1 = sp4[1];
-        int mat = __float_as_int(s1.z);
-        const float4 *mp = V.mats + 3 * (size_t)mat;
-        float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
-        int baseTex = __float_as_int(m0.w), emisTex = __float_as_int(m1.w);
-        float tu = 0.0f, tv = 0.0f;
-        if (baseTex >= 0 || emisTex >= 0) {
-            tu = (1 - h.u - h.v) * s0.x + h.u * s0.z + h.v * s1.x;
-            tv = (1 - h.u - h.v) * s0.y + h.u * s0.w + h.v * s1.y;
-        }
-        // UniversalMaterial::emitted, material.h:80-86
-        v3 emitted = mk3(m2.x, m2.y, m2.z);
-        if (emisTex >= 0) emitted = (tex_value(P, emisTex, tu, tv) * mk3(m1.x, m1.y, m1.z)) * 50.0f;
-        if (emitted.x > 0.0001f || emitted.y > 0.0001f || emitted.z > 0.0001f) {   // material.h:63
-            col = col + atten * emitted;                               // camera.h:72-74
-            need_new = true;
-            continue;
-        }
-        // material.h:67-68: a cosine sample that camera.h:65 overwrites; its 2 draws remain.
-        (void)xorwow_next(rng); (void)xorwow_next(rng);
-        v3 albedo = mk3(m0.x, m0.y, m0.z);
-        if (baseTex >= 0) albedo = albedo * tex_value(P, baseTex, tu, tv);
-        Onb uvw = onb_make(normal);                                    // cosine_pdf ctor, pdf.h:15-17
-        v3 dir;
-        if (xorwow_uniform(rng) < 0.5f) {                              // mixture_pdf::generate, pdf.h:66-72
-            float uu = xorwow_uniform(rng);                            // hitable_list::random, hitable_list.h:23-26
-            int idx = (int)truncf((float)((double)uu * P.light_index_scale));
-            const float4 *lp = V.lights + 5 * (size_t)idx;
-            float4 la = lp[0], ld = lp[3], le = lp[4];
-            float r1 = xorwow_uniform(rng), r2 = xorwow_uniform(rng);  // triangle::random, triangle.h:41-47
-            float sq = sqrtf(r1);
-            v3 lv0 = mk3(la.x, la.y, la.z), lv1 = mk3(ld.x, ld.y, ld.z), lv2 = mk3(ld.w, le.x, le.y);
-            v3 rp = ((1 - sq) * lv0 + (sq * (1 - r2)) * lv1) + (sq * r2) * lv2;
-            dir = rp - p;
-        } else {
-            float r1 = xorwow_uniform(rng), r2 = xorwow_uniform(rng);  // random_cosine_direction, helper_math.h:1519-1527
-            float z = sqrtf(1 - r2);
-            float phi = (float)(2 * M_PI * (double)r1);
-            float sn, cs;
-            pt_sincosf(phi, sn, cs);
-            float sq2 = sqrtf(r2);
-            float lx = cs * 2 * sq2, ly = sn * 2 * sq2;
-            dir = (lx * uvw.a0 + ly * uvw.a1) + z * uvw.a2;            // onb::local, onb.h:20-22
-        }
-        // hitable_list::pdf_value, hitable_list.h:16-22 -> triangle::pdf_value, triangle.h:32-40
-        float lsum = 0.0f;
-        for (int k = 0; k < P.n_lights; k++) {
-            const float4 *lp = V.lights + 5 * (size_t)k;
-            float4 la = lp[0], lb = lp[1], lc = lp[2], le = lp[4];
-            v3 v0 = mk3(la.x, la.y, la.z), e1 = mk3(la.w, lb.x, lb.y), e2 = mk3(lb.z, lb.w, lc.x);
-            v3 ln = mk3(lc.y, lc.z, lc.w);
-            float t, u, v;
-            n_light++;
-            float pdfv = 0.0f;
-            if (tri_hit(v0, e1, e2, p, dir, 0.001f, 3.402823466e+38f, t, u, v)) {
-                float distance_squared = t * t * dot(dir, dir);
-                float cosine = fabsf(dot(dir, ln) / length(dir));
-                pdfv = distance_squared / (cosine * le.z);
-            }
-            lsum += P.light_weight * pdfv;
-        }
-        v3 ndir = normalize(dir);
-        float cosv = dot(ndir, uvw.a2);                                // cosine_pdf::value, pdf.h:19-22
-        float cpdf = (cosv <= 0) ? 0.0f : (float)((double)cosv / M_PI);
-        float pdf_value = 0.5f * lsum + 0.5f * cpdf;                   // mixture_pdf::value, pdf.h:63-65
-        float cos2 = dot(normal, ndir);                                // scattering_pdf, material.h:88-91
-        float spdf = cos2 < 0 ? 0.0f : (float)((double)cos2 / M_PI);
-        atten = atten * ((albedo * spdf) / pdf_value);                 // camera.h:69
-        ro = p; rd = dir;
-        bounce++;
-        if (bounce >= P.depth) {
-            col = col + mk3(0.0f, 0.0f, 0.0f);                         // camera.h:82
-            need_new = true;
-        }
+        shade(L, P, V, h);
     }
 
-    if (in_frame) {
-        // :98-119
-        v3 q = (255.99f * col) / (float)P.spp;
-        int cr = f2i_rz_sat(q.x * 1.0f), cg = f2i_rz_sat(q.y * 1.0f), cb = f2i_rz_sat(q.z * 1.0f);
-        cr = min(255, cr); cg = min(255, cg); cb = min(255, cb);
-        P.rgb[3 * (size_t)pixel_index] = (uint8_t)cr;
-        P.rgb[3 * (size_t)pixel_index + 1] = (uint8_t)cg;
-        P.rgb[3 * (size_t)pixel_index + 2] = (uint8_t)cb;
-        P.yuv[pixel_index] = (uint8_t)(((66 * cr + 129 * cg + 25 * cb + 128) >> 8) + 16);
-        int blockRow = pixel_index / P.W, blockCol = pixel_index % P.W;
-        if (blockRow % 2 == 0 && blockCol % 2 == 0) {
-            int total = P.W * P.H, uvSize = total / 4;
-            int uvIndex = (blockRow / 2) * (P.W / 2) + (blockCol / 2);
-            P.yuv[total + uvIndex] = (uint8_t)(((-38 * cr - 74 * cg + 112 * cb + 128) >> 8) + 128);
-            P.yuv[total + uvSize + uvIndex] = (uint8_t)(((112 * cr - 94 * cg - 18 * cb + 128) >> 8) + 128);
-        }
-    }
+    if (in_frame) write_pixel(P, L.col, pixel_index);
 #ifdef PT_STAMPS
     {
         const unsigned long long total = __builtin_amdgcn_s_memtime() - stamp_begin;
@@ -694,16 +750,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
         }
     }
 #endif
-    // exact work counters: one atomic per wave per counter
-    uint32_t c0 = wave_sum(n_paths), c1 = wave_sum(n_seg), c2 = wave_sum(n_box), c3 = wave_sum(n_tri),
-             c4 = wave_sum(n_light);
-    if (lane == 0 && (c0 | c1)) {
-        atomicAdd(&P.counters[0], (unsigned long long)c0);
-        atomicAdd(&P.counters[1], (unsigned long long)c1);
-        atomicAdd(&P.counters[2], (unsigned long long)c2);
-        atomicAdd(&P.counters[3], (unsigned long long)c3);
-        atomicAdd(&P.counters[4], (unsigned long long)c4);
-    }
+    flush_counters(P, L, lane);
 }
 
 // ---- known-answer kernels (bit-exactness contract) -----------------------------------
