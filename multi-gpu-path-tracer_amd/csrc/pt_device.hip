@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -319,71 +320,91 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
 // order -- which is what the reference's in-order `t < ray_t.max` update computes over the
 // triangles it tests.  Differences from the reference are confined to rays for which the two
 // traversals test different triangles AND such a triangle wins.
+struct SahWalk {
+    uint32_t pair;
+    int sp;
+    float tbest;
+    uint32_t best_rank;
+    v3 inv;
+    Hit h;
+};
+
+__device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
+{
+    W.pair = 0; W.sp = 0; W.tbest = tmax0; W.best_rank = 0xFFFFFFFFu;
+    W.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    W.h.t = 0.0f; W.h.u = 0.0f; W.h.v = 0.0f; W.h.slot = -1;
+}
+
+// One node visit of the SAH walk (both child boxes, the triangles of hit leaf children, then
+// descend / pop).  Returns false when the walk is complete.
+__device__ __forceinline__ bool sah_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin,
+                                         uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
+{
+    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
+    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
+    const float4 *np = nodes + 4 * (size_t)W.pair;
+    const float4 a = np[0], b = np[1], c = np[2], lf = np[3];
+    const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
+    const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
+    const v3 inv = W.inv;
+    float tnl, tnr;
+    bool hl, hr;
+    {
+        float t1 = (a.x - o.x) * inv.x, t2 = (a.y - o.x) * inv.x, t3 = (a.z - o.y) * inv.y, t4 = (a.w - o.y) * inv.y;
+        float t5 = (b.x - o.z) * inv.z, t6 = (b.y - o.z) * inv.z;
+        tnl = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+        float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+        hl = (tf >= fmaxf(tnl, 0.0f)) & (tnl <= W.tbest);
+    }
+    {
+        float t1 = (b.z - o.x) * inv.x, t2 = (b.w - o.x) * inv.x, t3 = (c.x - o.y) * inv.y, t4 = (c.y - o.y) * inv.y;
+        float t5 = (c.z - o.z) * inv.z, t6 = (c.w - o.z) * inv.z;
+        tnr = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+        float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+        hr = (tf >= fmaxf(tnr, 0.0f)) & (tnr <= W.tbest);
+    }
+    n_box += 2;
+    // leaf children: one Moller-Trumbore loop over both ranges
+    uint32_t k0 = llink, n0 = (hl && lcnt) ? lcnt : 0u;
+    uint32_t k1 = rlink, n1 = (hr && rcnt) ? rcnt : 0u;
+    if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
+    while (n0 != 0) {
+        const float4 *tp = tris + 3 * (size_t)k0;
+        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+        float t, u, v;
+        n_tri++;
+        const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d, t, u, v);
+        const uint32_t rank = __float_as_uint(tc.y);
+        if (ok & (t > tmin) & ((t < W.tbest) | ((t == W.tbest) & (rank < W.best_rank)))) {
+            W.tbest = t; W.best_rank = rank; W.h.t = t; W.h.u = u; W.h.v = v; W.h.slot = (int)k0;
+        }
+        k0++; n0--;
+        if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
+    }
+    const bool gl = hl && lcnt == 0 && tnl <= W.tbest, gr = hr && rcnt == 0 && tnr <= W.tbest;
+    if (gl && gr) {
+        const bool left_first = tnl <= tnr;
+        stack[W.sp * stride] = left_first ? rlink : llink;
+        W.sp++;
+        W.pair = left_first ? llink : rlink;
+    } else if (gl || gr) {
+        W.pair = gl ? llink : rlink;
+    } else {
+        if (W.sp == 0) return false;
+        W.sp--;
+        W.pair = stack[W.sp * stride];
+    }
+    return true;
+}
+
 __device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
                                             uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
 {
-    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
-    float tbest = tmax0;
-    uint32_t best_rank = 0xFFFFFFFFu;
-    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
-    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
-    uint32_t pair = 0;
-    int sp = 0;
-    while (true) {
-        const float4 *np = nodes + 4 * (size_t)pair;
-        const float4 a = np[0], b = np[1], c = np[2], lf = np[3];
-        const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
-        const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
-        float tnl, tnr;
-        bool hl, hr;
-        {
-            float t1 = (a.x - o.x) * inv.x, t2 = (a.y - o.x) * inv.x, t3 = (a.z - o.y) * inv.y, t4 = (a.w - o.y) * inv.y;
-            float t5 = (b.x - o.z) * inv.z, t6 = (b.y - o.z) * inv.z;
-            tnl = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-            float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-            hl = (tf >= fmaxf(tnl, 0.0f)) & (tnl <= tbest);
-        }
-        {
-            float t1 = (b.z - o.x) * inv.x, t2 = (b.w - o.x) * inv.x, t3 = (c.x - o.y) * inv.y, t4 = (c.y - o.y) * inv.y;
-            float t5 = (c.z - o.z) * inv.z, t6 = (c.w - o.z) * inv.z;
-            tnr = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-            float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-            hr = (tf >= fmaxf(tnr, 0.0f)) & (tnr <= tbest);
-        }
-        n_box += 2;
-        // leaf children: one Moller-Trumbore loop over both ranges
-        uint32_t k0 = llink, n0 = (hl && lcnt) ? lcnt : 0u;
-        uint32_t k1 = rlink, n1 = (hr && rcnt) ? rcnt : 0u;
-        if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
-        while (n0 != 0) {
-            const float4 *tp = tris + 3 * (size_t)k0;
-            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-            float t, u, v;
-            n_tri++;
-            const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d, t, u, v);
-            const uint32_t rank = __float_as_uint(tc.y);
-            if (ok & (t > tmin) & ((t < tbest) | ((t == tbest) & (rank < best_rank)))) {
-                tbest = t; best_rank = rank; h.t = t; h.u = u; h.v = v; h.slot = (int)k0;
-            }
-            k0++; n0--;
-            if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
-        }
-        const bool gl = hl && lcnt == 0 && tnl <= tbest, gr = hr && rcnt == 0 && tnr <= tbest;
-        if (gl && gr) {
-            const bool left_first = tnl <= tnr;
-            stack[sp * stride] = left_first ? rlink : llink;
-            sp++;
-            pair = left_first ? llink : rlink;
-        } else if (gl || gr) {
-            pair = gl ? llink : rlink;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            pair = stack[sp * stride];
-        }
-    }
-    return h;
+    SahWalk W;
+    sah_begin(W, d, tmax0);
+    while (sah_step(P, W, o, d, tmin, stack, stride, n_box, n_tri)) {}
+    return W.h;
 }
 
 // BaseColorTexture::value + pixel_data, Texture.h:30-69.  The reference reads row `height`
@@ -753,6 +774,54 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
     flush_counters(P, L, lane);
 }
 
+// Render kernel for the SAH tree: same integrator, but the wave does not finish one ray segment
+// per trip.  Path lengths through a deep tree differ by orders of magnitude between the lanes of
+// a wave (a ray skimming the terrain visits hundreds of nodes, its neighbour ten), so the wave
+// alternates between (1) giving every idle lane its next ray, (2) node visits for all lanes that
+// are walking -- until at least half of those that were walking have finished -- and (3) shading
+// the finished ones, while the stragglers keep their traversal state (pair, LDS stack, closest
+// hit) across trips.  Per ray the sequence of tests is exactly traverse_sah's.
+template <int kDummy>
+__global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P)
+{
+    extern __shared__ float4 lds_raw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    int x, y, pixel_index;
+    const bool in_frame = lane_pixel(P, tid, x, y, pixel_index);
+    const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
+    const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
+    uint32_t *stack = LL.stack + tid;
+
+    PathState L;
+    path_init(L, P, pixel_index);
+    SahWalk W;
+    sah_begin(W, mk3(1.0f, 1.0f, 1.0f), 0.0f);
+    bool alive = in_frame && P.depth > 0;
+    bool walking = false;
+    while (true) {
+        if (alive && !walking) {
+            if (L.need_new && !start_path(L, P, x, y)) {
+                alive = false;
+            } else {
+                L.n_seg++;
+                sah_begin(W, L.rd, 3.402823466e+38f);
+                walking = true;
+            }
+        }
+        const int total = __popcll(__ballot(walking));
+        if (total == 0) break;                            // wave-uniform: nobody has work left
+        while (true) {
+            if (walking) walking = sah_step(P, W, L.ro, L.rd, 0.001f, stack, kBlock, L.n_box, L.n_tri);
+            const int still = __popcll(__ballot(walking));
+            if (still * 2 <= total) break;
+        }
+        if (alive && !walking) shade(L, P, V, W.h);
+    }
+    if (in_frame) write_pixel(P, L.col, pixel_index);
+    flush_counters(P, L, lane);
+}
+
 // ---- known-answer kernels (bit-exactness contract) -----------------------------------
 __global__ void kat_arith_kernel(int op, const float *a, const float *b, float *o0, float *o1, size_t n)
 {
@@ -862,6 +931,7 @@ struct pt_device {
     bool packed_queue = false;    // leaf-queue entries fit one dword (< 65536 triangles)
     int walk = 0;                 // traversal schedule: 0 per-lane, 1 uniform/mask, 2 uniform/stack, 3 SAH tree
     bool sah = false;             // uploaded with the opt-in SAH tree instead of the reference topology
+    bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
     int bvh_mode = 0;             // pt_set_bvh_mode: applies to the next pt_upload_scene
     int force_walk = -1;          // pt_set_traversal_mode: -1 auto, else the requested schedule
     int queue_entries = 8;        // per-lane leaf queue capacity (phase A -> phase B)
@@ -936,6 +1006,7 @@ pt_status pt_device_create(int device_index, pt_device **out)
     PT_HIP(hipSetDevice(device_index));
     std::unique_ptr<pt_device> d(new pt_device());
     d->index = device_index;
+    if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;      // diagnostic A/B switch
     PT_HIP(hipMalloc((void **)&d->d_counters, 8 * sizeof(unsigned long long)));
     PT_HIP(hipMemset(d->d_counters, 0, 8 * sizeof(unsigned long long)));
     *out = d.release();
@@ -1256,7 +1327,8 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         else { PT_HIP(hipEventCreate(&ev.first)); PT_HIP(hipEventCreate(&ev.second)); }
     }
     PT_HIP(hipEventRecord(ev.first, hs));
-    if (walk == 3) hipLaunchKernelGGL((dev::render_kernel<false, true, 3>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    if (walk == 3 && dev->sah_persistent) hipLaunchKernelGGL((dev::render_kernel_sah<0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (walk == 3) hipLaunchKernelGGL((dev::render_kernel<false, true, 3>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (walk == 1) hipLaunchKernelGGL((dev::render_kernel<false, true, 1>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (walk == 2) hipLaunchKernelGGL((dev::render_kernel<false, true, 2>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (stage && packed) hipLaunchKernelGGL((dev::render_kernel<true, true, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
