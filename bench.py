@@ -103,6 +103,9 @@ def main():
                          "makes every ray test ~730k triangles)")
     ap.add_argument("--width", type=int, default=0, help="diagnostic: override the config's width")
     ap.add_argument("--height", type=int, default=0, help="diagnostic: override the config's height")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank rehearsal on a box with ONE GPU: every rank uses cuda:0 and the exchange runs "
+                         "over gloo (RCCL needs one GPU per rank); checks the N > 1 code path, not its speed")
     ap.add_argument("--share-of", type=int, default=0,
                     help="diagnostic (1 GPU): time only rank 0's row bands of an N-rank split, print a "
                          "diagnostic line instead of the metric line")
@@ -117,10 +120,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is mandatory, there is no CPU fallback")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     kind, W, H, spp, depth, desc = CONFIGS[args.config]
@@ -177,10 +185,11 @@ def main():
     kernel_ms, launches = mgr.tracer.kernelTime()
     keys = ["paths", "segments", "box_tests", "tri_tests", "light_tests"]
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        rdev = "cpu" if args.rehearse else "cuda"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([float(cnt[k]) for k in keys], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([float(cnt[k]) for k in keys], dtype=torch.float64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total = {k: int(v) for k, v in zip(keys, tot.tolist())}
     else:
