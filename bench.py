@@ -31,6 +31,7 @@ CONFIGS = {
     "c2": ("box", 1920, 1080, 256, 8, "cornell_box.glb 1920x1080 256spp 8bounce"),
     "c3": ("duck", 1920, 1080, 256, 8, "cornell_duck.glb 1920x1080 256spp 8bounce"),
     "c4": ("terrain", 1920, 1080, 64, 8, "8M-triangle synthetic terrain 1920x1080 64spp 8bounce"),
+    "c5": ("box", 3840, 2160, 1024, 16, "cornell_box.glb 3840x2160 1024spp 16bounce"),
 }
 BOX_CAMERA = ((-255.5, 252.5, 700.0), (0.0, 0.0, -1.0))      # SURVEY.md 8d benchmark convention
 DUCK_CAMERA = ((0.0, 0.0, 0.5), (0.0, 0.0, -0.5))            # main.cu:40

@@ -188,3 +188,58 @@ def test_synthetic_terrain_bit_exact(pt, ob, gpu_device, mode):
     got = _render_gpu(pt, terr, cam, W, H, spp, depth, mode=mode)
     _assert_same(got, ref)
     assert got[0].max() > 0          # the terrain is lit
+
+
+def _textured_scene(pt):
+    """A hand-made scene that exercises what the Cornell models do not: a base-colour texture AND
+    an emissive texture, UVs outside [0,1) (fmod + clamp paths, Texture.h:38-58), the row-`height`
+    read (Texture.h:68), and the texture-pointer inheritance between materials
+    (DevicePathTracer.h:269-279: material 2 has no texture of its own and inherits material 1's)."""
+    rng = np.random.default_rng(5)
+    tex0 = rng.integers(0, 256, (8, 16, 3)).astype(np.float32)           # base colour, 16x8
+    tex1 = np.full((4, 4, 3), 255.0, np.float32)                          # emissive mask: one dark texel.  A path
+    tex1[1, 2] = 0.0                                                      # that lands on it scatters off the light's own
+    # plane, gets pdf 0 / 0 and poisons its pixel with NaN (-> byte 0): the reference's arithmetic, kept
+    mats = np.zeros(4, pt.capi.MATERIAL_DTYPE)
+    mats["baseColorTextureIdx"] = -1; mats["emissiveTextureIdx"] = -1
+    mats[0]["baseColor"] = (0.8, 0.8, 0.8)                                # plain floor
+    mats[1]["baseColor"] = (1.0, 0.9, 0.8); mats[1]["baseColorTextureIdx"] = 0
+    mats[2]["baseColor"] = (0.5, 1.0, 0.5)                                # inherits texture 0 (quirk)
+    mats[3]["baseColor"] = (0.0, 0.0, 0.0); mats[3]["emissiveFactor"] = (1.0, 0.8, 0.6); mats[3]["emissiveTextureIdx"] = 1
+    quads = [   # (corner, edge u, edge v, material, uv scale)
+        ((-4, 0, -4), (8, 0, 0), (0, 0, 8), 0, 1.0),                      # floor y=0, normal up?  (see winding below)
+        ((-4, 0, -4), (0, 5, 0), (8, 0, 0), 1, 2.5),                      # back wall z=-4, UVs up to 2.5 (wrap)
+        ((-4, 0, 4), (0, 5, 0), (0, 0, -8), 2, -1.5),                     # left wall x=-4, negative UVs
+        ((-1.5, 4.9, -1.5), (0, 0, 3), (3, 0, 0), 3, 1.0),                # textured light under the ceiling
+    ]
+    tris = []
+    for (c, eu, ev, m, s) in quads:
+        c, eu, ev = np.array(c, np.float32), np.array(eu, np.float32), np.array(ev, np.float32)
+        p = [c, c + eu, c + eu + ev, c + ev]
+        uv = [(0, 0), (s, 0), (s, s), (0, s)]
+        for (a, b, d) in ((0, 2, 1), (0, 3, 2)):
+            t = np.zeros((), pt.capi.TRIANGLE_DTYPE)
+            for name, k in (("v0", a), ("v1", b), ("v2", d)):
+                t[name]["position"] = p[k]; t[name]["texCoords"] = uv[k]
+            t["materialIdx"] = m
+            tris.append(t)
+    return np.array(tris, pt.capi.TRIANGLE_DTYPE), mats, [tex0, tex1]
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_textures_emissive_texture_and_inheritance_quirk(pt, ob, gpu_device, mode):
+    tris, mats, texs = _textured_scene(pt)
+    scene = pt.HostScene.from_arrays(tris, mats, texs)
+    osc = ob.OracleScene(tris, mats, texs)
+    cam = ((0.5, 2.0, 7.0), (0.0, 0.0, -1.0), 60.0, 60.0)
+    W, H, spp, depth = 72, 48, 6, 5
+    ref = osc.render(cam, W, H, spp, depth, threads=8)
+    got = _render_gpu(pt, scene, cam, W, H, spp, depth, mode=mode)
+    _assert_same(got, ref)
+    assert len(np.unique(ref[0].reshape(-1, 3), axis=0)) > 50         # textured, lit, not flat
+
+
+def test_c5_parameters_small_frame(pt, box_scene, box_oracle, gpu_device):
+    """BASELINE.json configs[4] parameters (1024 spp, 16 bounces) on a small frame."""
+    ref = box_oracle.render(BOX_CAMERA, 32, 16, 1024, 16, threads=8)
+    _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, 32, 16, 1024, 16), ref)
