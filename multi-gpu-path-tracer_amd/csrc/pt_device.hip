@@ -20,692 +20,13 @@
 #include <vector>
 
 #include "pt_kernels.h"
+#include "pt_walk.h"
+#include "pt_shade.h"
 
 namespace pt {
 
 // ====================================================================== device code ==
 namespace dev {
-
-constexpr int kWave = 64;
-constexpr int kWavesPerBlock = 4;
-constexpr int kBlock = kWave * kWavesPerBlock;
-
-struct Hit {
-    float t, u, v;
-    int slot;          // leaf-order triangle slot of the closest hit, -1 = none
-};
-
-// aabb::hit, aabb.h:38-66 (ray_t / rec ignored there too).  inv = 1.0f / direction.
-__device__ __forceinline__ bool box_hit(float xmin, float xmax, float ymin, float ymax, float zmin,
-                                        float zmax, v3 o, v3 inv)
-{
-    float t1 = (xmin - o.x) * inv.x, t2 = (xmax - o.x) * inv.x;
-    float t3 = (ymin - o.y) * inv.y, t4 = (ymax - o.y) * inv.y;
-    float t5 = (zmin - o.z) * inv.z, t6 = (zmax - o.z) * inv.z;
-    float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-    float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-    return !(tmax < 0) && !(tmin > tmax);
-}
-
-// triangle::hit, triangle.h:63-113 (Moller-Trumbore) on a precomputed (v0, e1, e2) record.
-// Returns true when the candidate is accepted for the interval (tmin, tmax); t/u/v out.
-__device__ __forceinline__ bool tri_hit(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float tmin, float tmax,
-                                        float &t_out, float &u_out, float &v_out)
-{
-    v3 pvec = cross(d, e2);
-    float det = dot(e1, pvec);
-    // triangle.h:78 compares in double against +-1e-8; for a float det that is exactly
-    // |det| <= 1e-8f (1e-8f < 1e-8 < nextafter(1e-8f)).
-    bool ok = !(det <= 1e-8f && det >= -1e-8f);
-    float inv_det = 1.0f / det;                       // :84 (double divide == IEEE 1.0f/det)
-    v3 tvec = o - v0;
-    float u = dot(tvec, pvec) * inv_det;
-    ok = ok && !(u < 0 || u > 1);
-    v3 qvec = cross(tvec, e1);
-    float v = dot(d, qvec) * inv_det;
-    ok = ok && !(v < 0 || u + v > 1);
-    float t = dot(e2, qvec) * inv_det;
-    ok = ok && (t < tmax && t > tmin);
-    t_out = t; u_out = u; v_out = v;
-    return ok;
-}
-
-// Moller-Trumbore arithmetic of triangle.h:63-98 without the interval test: the u/v/t values and
-// whether det, u and v pass (same operations, same order as tri_hit).
-__device__ __forceinline__ bool mt_eval(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float &t, float &u, float &v)
-{
-    v3 pvec = cross(d, e2);
-    float det = dot(e1, pvec);
-    bool ok = !((det <= 1e-8f) & (det >= -1e-8f));
-    float inv_det = 1.0f / det;
-    v3 tvec = o - v0;
-    u = dot(tvec, pvec) * inv_det;
-    ok = ok & !((u < 0) | (u > 1));
-    v3 qvec = cross(tvec, e1);
-    v = dot(d, qvec) * inv_det;
-    ok = ok & !((v < 0) | (u + v > 1));
-    t = dot(e2, qvec) * inv_det;
-    return ok;
-}
-
-__device__ __forceinline__ void load_tri(const TriIsect *tris, int slot, v3 &v0, v3 &e1, v3 &e2)
-{
-    const float4 *p = reinterpret_cast<const float4 *>(tris + slot);
-    float4 a = p[0], b = p[1], c = p[2];
-    v0 = mk3(a.x, a.y, a.z);
-    e1 = mk3(a.w, b.x, b.y);
-    e2 = mk3(b.z, b.w, c.x);
-}
-
-// Scene accessors: the node and triangle arrays are read either from HBM (through L1/L2) or,
-// when the launch staged them, from LDS (ds_read_b128).
-template <bool kLds>
-struct SceneView {
-    const float4 *nodes;      // NodePair records, 4 x float4 each
-    const float4 *tris;       // TriIsect records, 3 x float4 each
-};
-
-// BVH::hit, bvh.h:178-246, split into two phases per ray segment:
-//   phase A  walks the boxes in the reference's order (both children's boxes per visit,
-//            left-first descent, right sibling pushed on the per-lane LDS stack) and only
-//            RECORDS the leaves it would test, in visit order, in a per-lane LDS queue;
-//   phase B  runs Moller-Trumbore over the queued leaves in that same order.
-// This is the reference's exact sequence of triangle tests (aabb::hit ignores ray_t, so the
-// boxes never depend on earlier triangle results); it only keeps the lanes of a wave in the
-// same code at the same time.  When a lane's queue is full the wave drains (phase B) and
-// resumes phase A where it stopped.
-// `stack` / `queue` are this lane's LDS columns (element stride = `stride` lanes).
-// Leaf-queue entry: {first slot, triangle count}.  Scenes with < 65536 triangles pack it into
-// one dword (half the LDS), larger scenes use two.
-template <bool kPacked> struct QueueEntry;
-template <> struct QueueEntry<true> {
-    typedef uint32_t type;
-    static __device__ __forceinline__ type make(uint32_t first, uint32_t count) { return first | (count << 16); }
-    static __device__ __forceinline__ void split(type e, uint32_t &first, uint32_t &count) { first = e & 0xFFFFu; count = e >> 16; }
-};
-template <> struct QueueEntry<false> {
-    typedef uint2 type;
-    static __device__ __forceinline__ type make(uint32_t first, uint32_t count) { return make_uint2(first, count); }
-    static __device__ __forceinline__ void split(type e, uint32_t &first, uint32_t &count) { first = e.x; count = e.y; }
-};
-
-template <bool kLds, bool kPacked>
-__device__ __forceinline__ Hit traverse(const SceneView<kLds> S, v3 o, v3 d, float tmin, float tmax0,
-                                        uint32_t *stack, typename QueueEntry<kPacked>::type *queue, int stride,
-                                        int qcap, uint32_t &n_box, uint32_t &n_tri)
-{
-    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
-    float tmax = tmax0;
-    v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    uint32_t pair = 0;
-    int sp = 0;
-    bool walking = true;
-    while (walking) {
-        // ---------------- phase A: boxes -> leaf queue
-        int qn = 0;
-        while (walking && qn + 2 <= qcap) {
-            const float4 *np = S.nodes + 4 * (size_t)pair;
-            float4 a = np[0], b = np[1], c = np[2];
-            float4 lf = np[3];
-            uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
-            uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
-            bool ol = box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
-            bool orr = box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
-            n_box += 2;
-            if (ol && lcnt) { queue[qn * stride] = QueueEntry<kPacked>::make(llink, lcnt); qn++; }
-            if (orr && rcnt) { queue[qn * stride] = QueueEntry<kPacked>::make(rlink, rcnt); qn++; }
-            bool tl = ol && lcnt == 0, tr = orr && rcnt == 0;
-            if (tl && tr) {
-                stack[sp * stride] = rlink;
-                sp++;
-                pair = llink;
-            } else if (tl) {
-                pair = llink;
-            } else if (tr) {
-                pair = rlink;
-            } else if (sp == 0) {
-                walking = false;
-            } else {
-                sp--;
-                pair = stack[sp * stride];
-            }
-        }
-        // ---------------- phase B: triangles of the queued leaves, in queue order
-        int qi = 0;
-        uint32_t k = 0, n = 0;
-        while (true) {
-            if (n == 0) {
-                if (qi == qn) break;
-                QueueEntry<kPacked>::split(queue[qi * stride], k, n);
-                qi++;
-            }
-            const float4 *tp = S.tris + 3 * (size_t)k;
-            float4 ta = tp[0], tb = tp[1];
-            float e2z = reinterpret_cast<const float *>(tp + 2)[0];
-            float t, u, v;
-            n_tri++;
-            if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
-                tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k;
-            }
-            k++; n--;
-        }
-    }
-    return h;
-}
-
-// Wave-uniform traversal for scenes whose whole tree is at most 64 inner nodes (Cornell box:
-// 10).  All lanes of the wave walk the SAME node / triangle at the same time, in the
-// reference's visit order (NodePairs are numbered in DFS pre-order = visit order), each lane
-// carrying a 64-bit "this pair is on my path" mask instead of a stack.  Because the loop
-// counters are wave-uniform, node and triangle records arrive through the scalar cache
-// (s_load) and sit in SGPRs as instruction operands: no LDS, no per-lane queue, no divergent
-// loop trip counts.  A pair (or a leaf) that no lane of the wave reaches is skipped with one
-// scalar branch.  Per lane the sequence of slab and triangle tests is exactly bvh.h:178-246.
-__device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
-                                                uint32_t &n_box, uint32_t &n_tri)
-{
-    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
-    float tmax = tmax0;
-    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
-    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
-    unsigned long long act = 1ull;                       // bit p: pair p is on this lane's path
-    const int n_pairs = P.n_pairs;
-    for (int p = 0; p < n_pairs; p++) {
-        const bool on = (act >> p) & 1ull;
-        if (__ballot(on) == 0ull) continue;              // nobody in the wave visits pair p
-        const float4 a = nodes[4 * p], b = nodes[4 * p + 1], c = nodes[4 * p + 2], lf = nodes[4 * p + 3];
-        const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
-        const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
-        const bool hl = on && box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
-        const bool hr = on && box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
-        if (on) n_box += 2;
-#pragma unroll
-        for (int side = 0; side < 2; side++) {
-            const bool hit = side ? hr : hl;
-            const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
-            if (cnt == 0) {                              // inner child: mark its pair
-                if (hit) act |= 1ull << link;
-            } else if (__ballot(hit) != 0ull) {          // leaf child somebody hits
-                for (uint32_t k = link; k < link + cnt; k++) {
-                    const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
-                    const float e2z = reinterpret_cast<const float *>(tris + 3 * k + 2)[0];
-                    if (hit) {
-                        float t, u, v;
-                        n_tri++;
-                        if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
-                            tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    return h;
-}
-
-// The same wave-uniform walk for bigger trees (cornell_duck: 332 inner nodes, leaves of up to
-// 1603 triangles): instead of a 64-bit mask each lane keeps the NEXT pair on its path plus its
-// pending right siblings on the per-lane LDS stack.  Pairs are numbered in visit order, so the
-// pending set is a stack and `next` is always its minimum; the wave scans p upward and a lane
-// takes part in pair p iff next == p.  Leaves are tested in lockstep by every lane that hit
-// their box, with triangle records coming through the scalar cache -- a 1603-triangle leaf costs
-// 1603 uniform trips instead of 1603 divergent gather trips per lane.  Cost per ray segment is
-// the UNION of the lanes' paths, so the host picks this walk only for small / medium trees.
-__device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
-                                                      uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
-{
-    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
-    float tmax = tmax0;
-    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
-    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
-    uint32_t next = 0;
-    int sp = 0;
-    bool walking = true;
-    const int n_pairs = P.n_pairs;
-    for (int p = 0; p < n_pairs; p++) {
-        const bool on = walking && next == (uint32_t)p;
-        if (__ballot(on) == 0ull) {
-            if (__ballot(walking) == 0ull) break;        // every lane of the wave is done
-            continue;
-        }
-        const float4 a = nodes[4 * p], b = nodes[4 * p + 1], c = nodes[4 * p + 2], lf = nodes[4 * p + 3];
-        const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
-        const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
-        const bool hl = on && box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
-        const bool hr = on && box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
-        if (on) {
-            n_box += 2;
-            const bool tl = hl && lcnt == 0, tr = hr && rcnt == 0;
-            if (tl && tr) {
-                stack[sp * stride] = rlink;
-                sp++;
-                next = llink;
-            } else if (tl || tr) {
-                next = tl ? llink : rlink;
-            } else if (sp == 0) {
-                walking = false;
-            } else {
-                sp--;
-                next = stack[sp * stride];
-            }
-        }
-#pragma unroll
-        for (int side = 0; side < 2; side++) {
-            const bool hit = side ? hr : hl;
-            const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
-            if (cnt != 0 && __ballot(hit) != 0ull) {
-                for (uint32_t k = link; k < link + cnt; k++) {
-                    const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
-                    const float e2z = reinterpret_cast<const float *>(tris + 3 * k + 2)[0];
-                    if (hit) {
-                        float t, u, v;
-                        n_tri++;
-                        if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
-                            tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    return h;
-}
-
-// Opt-in walk over the SAH tree (pt_set_bvh_mode(dev, 1); not the reference's traversal): per-lane
-// LDS stack, nearer child first, subtrees whose (epsilon-inflated) box starts beyond the closest
-// hit so far are pruned.  Triangles are tested with the same Moller-Trumbore arithmetic and the
-// closest hit is min over (t, rank) -- rank = the triangle's position in the reference's visit
-// order -- which is what the reference's in-order `t < ray_t.max` update computes over the
-// triangles it tests.  Differences from the reference are confined to rays for which the two
-// traversals test different triangles AND such a triangle wins.
-struct SahWalk {
-    uint32_t pair;
-    int sp;
-    float tbest;
-    uint32_t best_rank;
-    v3 inv;
-    Hit h;
-};
-
-__device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
-{
-    W.pair = 0; W.sp = 0; W.tbest = tmax0; W.best_rank = 0xFFFFFFFFu;
-    W.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    W.h.t = 0.0f; W.h.u = 0.0f; W.h.v = 0.0f; W.h.slot = -1;
-}
-
-// One node visit of the SAH walk (both child boxes, the triangles of hit leaf children, then
-// descend / pop).  Returns false when the walk is complete.
-__device__ __forceinline__ bool sah_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin,
-                                         uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
-{
-    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
-    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
-    const float4 *np = nodes + 4 * (size_t)W.pair;
-    const float4 a = np[0], b = np[1], c = np[2], lf = np[3];
-    const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
-    const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
-    const v3 inv = W.inv;
-    float tnl, tnr;
-    bool hl, hr;
-    {
-        float t1 = (a.x - o.x) * inv.x, t2 = (a.y - o.x) * inv.x, t3 = (a.z - o.y) * inv.y, t4 = (a.w - o.y) * inv.y;
-        float t5 = (b.x - o.z) * inv.z, t6 = (b.y - o.z) * inv.z;
-        tnl = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-        float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-        hl = (tf >= fmaxf(tnl, 0.0f)) & (tnl <= W.tbest);
-    }
-    {
-        float t1 = (b.z - o.x) * inv.x, t2 = (b.w - o.x) * inv.x, t3 = (c.x - o.y) * inv.y, t4 = (c.y - o.y) * inv.y;
-        float t5 = (c.z - o.z) * inv.z, t6 = (c.w - o.z) * inv.z;
-        tnr = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-        float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-        hr = (tf >= fmaxf(tnr, 0.0f)) & (tnr <= W.tbest);
-    }
-    n_box += 2;
-    // leaf children: one Moller-Trumbore loop over both ranges
-    uint32_t k0 = llink, n0 = (hl && lcnt) ? lcnt : 0u;
-    uint32_t k1 = rlink, n1 = (hr && rcnt) ? rcnt : 0u;
-    if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
-    while (n0 != 0) {
-        const float4 *tp = tris + 3 * (size_t)k0;
-        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-        float t, u, v;
-        n_tri++;
-        const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d, t, u, v);
-        const uint32_t rank = __float_as_uint(tc.y);
-        if (ok & (t > tmin) & ((t < W.tbest) | ((t == W.tbest) & (rank < W.best_rank)))) {
-            W.tbest = t; W.best_rank = rank; W.h.t = t; W.h.u = u; W.h.v = v; W.h.slot = (int)k0;
-        }
-        k0++; n0--;
-        if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
-    }
-    const bool gl = hl && lcnt == 0 && tnl <= W.tbest, gr = hr && rcnt == 0 && tnr <= W.tbest;
-    if (gl && gr) {
-        const bool left_first = tnl <= tnr;
-        stack[W.sp * stride] = left_first ? rlink : llink;
-        W.sp++;
-        W.pair = left_first ? llink : rlink;
-    } else if (gl || gr) {
-        W.pair = gl ? llink : rlink;
-    } else {
-        if (W.sp == 0) return false;
-        W.sp--;
-        W.pair = stack[W.sp * stride];
-    }
-    return true;
-}
-
-__device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
-                                            uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
-{
-    SahWalk W;
-    sah_begin(W, d, tmax0);
-    while (sah_step(P, W, o, d, tmin, stack, stride, n_box, n_tri)) {}
-    return W.h;
-}
-
-// BaseColorTexture::value + pixel_data, Texture.h:30-69.  The reference reads row `height`
-// (one past the end) when j == 0; that row is clamped to height-1 here.
-__device__ __forceinline__ v3 tex_value(const RenderParams &P, int tex, float u, float v)
-{
-    TexDesc td = P.texs[tex];
-    if (td.h <= 0) return mk3((float)242 / 255, (float)45 / 255, (float)27 / 255);
-    u = fmodf(u, 1.0f); v = fmodf(v, 1.0f);
-    int i = (int)(u * (float)td.w);
-    int j = (int)(v * (float)td.h);
-    int x = i < 0 ? 0 : (i < td.w ? i : td.w - 1);
-    int y = j < 0 ? 0 : (j < td.h ? j : td.h - 1);
-    y = td.h - y;
-    if (y > td.h - 1) y = td.h - 1;
-    const float *px = P.texels + td.offset + 3 * ((size_t)y * (size_t)td.w + (size_t)x);
-    double cs = 1.0 / 255.0;
-    return mk3((float)(cs * (double)px[0]), (float)(cs * (double)px[1]), (float)(cs * (double)px[2]));
-}
-
-struct Onb { v3 a0, a1, a2; };
-// onb::onb, onb.h:8-13
-__device__ __forceinline__ Onb onb_make(v3 n)
-{
-    Onb b;
-    b.a2 = normalize(n);
-    v3 a = fabsf(b.a2.x) > 0.9f ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
-    b.a1 = normalize(cross(b.a2, a));
-    b.a0 = cross(b.a2, b.a1);
-    return b;
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// Dynamic LDS layout of a workgroup: [staged NodePairs][staged TriIsects] (only when the scene
-// is staged) [traversal stacks: stack_entries x blockDim dwords][leaf queues: queue_entries x
-// blockDim uint2].  All sections are 16-byte aligned.
-struct LdsLayout {
-    const float4 *nodes;
-    const float4 *tris;
-    uint32_t *stack;
-    void *queue;
-    float4 *tail;             // first float4 after the traversal sections (shading tables)
-};
-
-template <bool kLds>
-__device__ __forceinline__ LdsLayout lds_carve(const RenderParams &P, float4 *base, int block)
-{
-    LdsLayout L;
-    size_t off = 0;                                  // in float4 units
-    L.nodes = base;
-    if (kLds) off += (size_t)P.n_pairs * 4;
-    L.tris = base + off;
-    if (kLds) off += (size_t)P.n_tris * 3;
-    L.stack = reinterpret_cast<uint32_t *>(base + off);
-    off += ((size_t)P.stack_entries * block + 3) / 4;
-    L.queue = reinterpret_cast<void *>(base + off);
-    off += ((size_t)P.queue_entries * block * P.queue_dwords + 3) / 4;
-    L.tail = base + off;
-    return L;
-}
-
-// Cooperative copy of the node and triangle arrays into LDS (scene fits: Cornell box 2.4 KB).
-template <bool kLds>
-__device__ __forceinline__ SceneView<kLds> stage_scene(const RenderParams &P, float4 *base, int tid, int block)
-{
-    SceneView<kLds> S;
-    if (kLds) {
-        const float4 *gn = reinterpret_cast<const float4 *>(P.nodes);
-        const float4 *gt = reinterpret_cast<const float4 *>(P.tris);
-        const int nn = P.n_pairs * 4, nt = P.n_tris * 3;
-        for (int i = tid; i < nn; i += block) base[i] = gn[i];
-        for (int i = tid; i < nt; i += block) base[nn + i] = gt[i];
-        __syncthreads();
-        S.nodes = base;
-        S.tris = base + nn;
-    } else {
-        S.nodes = reinterpret_cast<const float4 *>(P.nodes);
-        S.tris = reinterpret_cast<const float4 *>(P.tris);
-    }
-    return S;
-}
-
-// Shading tables (TriShade per slot, MatRec, LightRec).  Fetching them from HBM/L2 costs a chain
-// of three dependent loads per hit; small scenes keep them in LDS after the traversal sections.
-struct ShadeView {
-    const float4 *shade;      // 3 x float4 per slot
-    const float4 *mats;       // 3 x float4 per material
-    const float4 *lights;     // 5 x float4 per light
-};
-
-__device__ __forceinline__ ShadeView stage_shade(const RenderParams &P, float4 *lds, int tid, int block)
-{
-    ShadeView V;
-    if (P.shade_lds) {
-        const float4 *gs = reinterpret_cast<const float4 *>(P.shade);
-        const float4 *gm = reinterpret_cast<const float4 *>(P.mats);
-        const float4 *gl = reinterpret_cast<const float4 *>(P.lights);
-        const int ns = P.n_tris * 3, nm = P.n_mats * 3, nl = P.n_lights * 5;
-        for (int i = tid; i < ns; i += block) lds[i] = gs[i];
-        for (int i = tid; i < nm; i += block) lds[ns + i] = gm[i];
-        for (int i = tid; i < nl; i += block) lds[ns + nm + i] = gl[i];
-        __syncthreads();
-        V.shade = lds; V.mats = lds + ns; V.lights = lds + ns + nm;
-    } else {
-        V.shade = reinterpret_cast<const float4 *>(P.shade);
-        V.mats = reinterpret_cast<const float4 *>(P.mats);
-        V.lights = reinterpret_cast<const float4 *>(P.lights);
-    }
-    return V;
-}
-
-// render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
-// camera::ray_color (camera.h:49-83) flattened into a per-lane state machine.
-// Per-lane integrator state of camera::ray_color (camera.h:49-83) and of render's sample loop
-// (DevicePathTracer.h:80-87), plus this lane's exact work counters.
-struct PathState {
-    xorwow rng;
-    v3 col, atten, ro, rd;
-    int s;                 // samples started
-    unsigned bounce;       // segments traced on the current path
-    bool need_new;         // the next trip starts a new sample
-    uint32_t n_paths, n_seg, n_box, n_tri, n_light;
-};
-
-__device__ __forceinline__ void path_init(PathState &L, const RenderParams &P, int pixel_index)
-{
-    xorwow_init(L.rng, (uint64_t)(long long)(1984 + pixel_index));   // :54 seed, :80 state copy
-    L.col = mk3(0.0f, 0.0f, 0.0f);
-    L.atten = mk3(1.0f, 1.0f, 1.0f);
-    L.ro = P.cam.origin; L.rd = mk3(0.0f, 0.0f, 0.0f);
-    L.s = 0; L.bounce = 0; L.need_new = true;
-    L.n_paths = L.n_seg = L.n_box = L.n_tri = L.n_light = 0;
-}
-
-// Starts the next sample of pixel (x, y): DevicePathTracer.h:84-86 + camera::get_ray camera.h:95-97.
-// Returns false when all samples are done.
-__device__ __forceinline__ bool start_path(PathState &L, const RenderParams &P, int x, int y)
-{
-    if (L.s >= P.spp) return false;
-    float u = ((float)x + xorwow_uniform(L.rng)) / (float)(unsigned)P.W;
-    float v = ((float)y + xorwow_uniform(L.rng)) / (float)(unsigned)P.H;
-    L.ro = P.cam.origin;
-    L.rd = ((P.cam.llc + u * P.cam.horizontal) + v * P.cam.vertical) - P.cam.origin;
-    L.atten = mk3(1.0f, 1.0f, 1.0f);
-    L.bounce = 0;
-    L.s++;
-    L.n_paths++;
-    L.need_new = false;
-    return true;
-}
-
-// What camera::ray_color does with the result of one BVH::hit (camera.h:55-80): miss, emissive
-// hit, or a scattering bounce that sets up the next ray segment.
-__device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const ShadeView &V, const Hit &h)
-{
-    if (h.slot < 0) {
-        L.col = L.col + mk3(0.0f, 0.0f, 0.0f) * L.atten;                // camera.h:78-79
-        L.need_new = true;
-        return;
-    }
-    // hit_record completion, triangle.h:100-108
-    const float4 tc = V.shade[3 * (size_t)h.slot + 2];
-    v3 normal = mk3(tc.x, tc.y, tc.z);
-    v3 p = L.ro + h.t * L.rd;
-    const float4 *sp4 = V.shade + 3 * (size_t)h.slot;
-    float4 s0 = sp4[0], s1 = sp4[1];
-    int mat = __float_as_int(s1.z);
-    const float4 *mp = V.mats + 3 * (size_t)mat;
-    float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
-    int baseTex = __float_as_int(m0.w), emisTex = __float_as_int(m1.w);
-    float tu = 0.0f, tv = 0.0f;
-    if (baseTex >= 0 || emisTex >= 0) {
-        tu = (1 - h.u - h.v) * s0.x + h.u * s0.z + h.v * s1.x;
-        tv = (1 - h.u - h.v) * s0.y + h.u * s0.w + h.v * s1.y;
-    }
-    // UniversalMaterial::emitted, material.h:80-86
-    v3 emitted = mk3(m2.x, m2.y, m2.z);
-    if (emisTex >= 0) emitted = (tex_value(P, emisTex, tu, tv) * mk3(m1.x, m1.y, m1.z)) * 50.0f;
-    if (emitted.x > 0.0001f || emitted.y > 0.0001f || emitted.z > 0.0001f) {   // material.h:63
-        L.col = L.col + L.atten * emitted;                               // camera.h:72-74
-        L.need_new = true;
-        return;
-    }
-    // material.h:67-68: a cosine sample that camera.h:65 overwrites; its 2 draws remain.
-    (void)xorwow_next(L.rng); (void)xorwow_next(L.rng);
-    v3 albedo = mk3(m0.x, m0.y, m0.z);
-    if (baseTex >= 0) albedo = albedo * tex_value(P, baseTex, tu, tv);
-    Onb uvw = onb_make(normal);                                    // cosine_pdf ctor, pdf.h:15-17
-    v3 dir;
-    if (xorwow_uniform(L.rng) < 0.5f) {                              // mixture_pdf::generate, pdf.h:66-72
-        float uu = xorwow_uniform(L.rng);                            // hitable_list::random, hitable_list.h:23-26
-        int idx = (int)truncf((float)((double)uu * P.light_index_scale));
-        const float4 *lp = V.lights + 5 * (size_t)idx;
-        float4 la = lp[0], ld = lp[3], le = lp[4];
-        float r1 = xorwow_uniform(L.rng), r2 = xorwow_uniform(L.rng);  // triangle::random, triangle.h:41-47
-        float sq = sqrtf(r1);
-        v3 lv0 = mk3(la.x, la.y, la.z), lv1 = mk3(ld.x, ld.y, ld.z), lv2 = mk3(ld.w, le.x, le.y);
-        v3 rp = ((1 - sq) * lv0 + (sq * (1 - r2)) * lv1) + (sq * r2) * lv2;
-        dir = rp - p;
-    } else {
-        float r1 = xorwow_uniform(L.rng), r2 = xorwow_uniform(L.rng);  // random_cosine_direction, helper_math.h:1519-1527
-        float z = sqrtf(1 - r2);
-        float phi = (float)(2 * M_PI * (double)r1);
-        float sn, cs;
-        pt_sincosf(phi, sn, cs);
-        float sq2 = sqrtf(r2);
-        float lx = cs * 2 * sq2, ly = sn * 2 * sq2;
-        dir = (lx * uvw.a0 + ly * uvw.a1) + z * uvw.a2;            // onb::local, onb.h:20-22
-    }
-    // hitable_list::pdf_value, hitable_list.h:16-22 -> triangle::pdf_value, triangle.h:32-40
-    float lsum = 0.0f;
-    for (int k = 0; k < P.n_lights; k++) {
-        const float4 *lp = V.lights + 5 * (size_t)k;
-        float4 la = lp[0], lb = lp[1], lc = lp[2], le = lp[4];
-        v3 v0 = mk3(la.x, la.y, la.z), e1 = mk3(la.w, lb.x, lb.y), e2 = mk3(lb.z, lb.w, lc.x);
-        v3 ln = mk3(lc.y, lc.z, lc.w);
-        float t, u, v;
-        L.n_light++;
-        float pdfv = 0.0f;
-        if (tri_hit(v0, e1, e2, p, dir, 0.001f, 3.402823466e+38f, t, u, v)) {
-            float distance_squared = t * t * dot(dir, dir);
-            float cosine = fabsf(dot(dir, ln) / length(dir));
-            pdfv = distance_squared / (cosine * le.z);
-        }
-        lsum += P.light_weight * pdfv;
-    }
-    v3 ndir = normalize(dir);
-    float cosv = dot(ndir, uvw.a2);                                // cosine_pdf::value, pdf.h:19-22
-    float cpdf = (cosv <= 0) ? 0.0f : (float)((double)cosv / M_PI);
-    float pdf_value = 0.5f * lsum + 0.5f * cpdf;                   // mixture_pdf::value, pdf.h:63-65
-    float cos2 = dot(normal, ndir);                                // scattering_pdf, material.h:88-91
-    float spdf = cos2 < 0 ? 0.0f : (float)((double)cos2 / M_PI);
-    L.atten = L.atten * ((albedo * spdf) / pdf_value);                 // camera.h:69
-    L.ro = p; L.rd = dir;
-    L.bounce++;
-    if (L.bounce >= P.depth) {
-        L.col = L.col + mk3(0.0f, 0.0f, 0.0f);                         // camera.h:82
-        L.need_new = true;
-    }
-}
-
-// Quantisation + RGB / YUV420 store of one pixel, DevicePathTracer.h:98-119.
-__device__ __forceinline__ void write_pixel(const RenderParams &P, v3 col, int pixel_index)
-{
-{
-    // :98-119
-    v3 q = (255.99f * col) / (float)P.spp;
-    int cr = f2i_rz_sat(q.x * 1.0f), cg = f2i_rz_sat(q.y * 1.0f), cb = f2i_rz_sat(q.z * 1.0f);
-    cr = min(255, cr); cg = min(255, cg); cb = min(255, cb);
-    P.rgb[3 * (size_t)pixel_index] = (uint8_t)cr;
-    P.rgb[3 * (size_t)pixel_index + 1] = (uint8_t)cg;
-    P.rgb[3 * (size_t)pixel_index + 2] = (uint8_t)cb;
-    P.yuv[pixel_index] = (uint8_t)(((66 * cr + 129 * cg + 25 * cb + 128) >> 8) + 16);
-    int blockRow = pixel_index / P.W, blockCol = pixel_index % P.W;
-    if (blockRow % 2 == 0 && blockCol % 2 == 0) {
-        int total = P.W * P.H, uvSize = total / 4;
-        int uvIndex = (blockRow / 2) * (P.W / 2) + (blockCol / 2);
-        P.yuv[total + uvIndex] = (uint8_t)(((-38 * cr - 74 * cg + 112 * cb + 128) >> 8) + 128);
-        P.yuv[total + uvSize + uvIndex] = (uint8_t)(((112 * cr - 94 * cg - 18 * cb + 128) >> 8) + 128);
-    }
-}
-}
-
-// Exact work counters: one atomic per wave per counter.
-__device__ __forceinline__ void flush_counters(const RenderParams &P, const PathState &L, int lane)
-{
-    uint32_t c0 = wave_sum(L.n_paths), c1 = wave_sum(L.n_seg), c2 = wave_sum(L.n_box), c3 = wave_sum(L.n_tri),
-             c4 = wave_sum(L.n_light);
-    if (lane == 0 && (c0 | c1)) {
-        atomicAdd(&P.counters[0], (unsigned long long)c0);
-        atomicAdd(&P.counters[1], (unsigned long long)c1);
-        atomicAdd(&P.counters[2], (unsigned long long)c2);
-        atomicAdd(&P.counters[3], (unsigned long long)c3);
-        atomicAdd(&P.counters[4], (unsigned long long)c4);
-    }
-}
-
-// Pixel of this lane: 8x8 tile per wave; in row-band mode (pt_render_bands_async) local row j is row
-// (j % band_rows) of this rank's (j / band_rows)-th band, band b of the frame (fb rows, 0 = top)
-// belonging to rank b % band_ranks.
-__device__ __forceinline__ bool lane_pixel(const RenderParams &P, int tid, int &x, int &y, int &pixel_index)
-{
-    const int lane = tid & (kWave - 1);
-    const int wave = tid / kWave;
-    const int tile = blockIdx.x * kWavesPerBlock + wave;
-    const int tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
-    const int i = tile_x * 8 + (lane & 7), j = tile_y * 8 + (lane >> 3);
-    const bool in_task = (tile_y < P.tiles_y) && (i < P.task_w) && (j < P.task_h);
-    x = P.task_ox + i; y = P.task_oy + j;
-    if (P.band_ranks > 0) {
-        const int fb_row = ((j / P.band_rows) * P.band_ranks + P.band_rank) * P.band_rows + (j % P.band_rows);
-        y = P.H - 1 - fb_row;
-    }
-    pixel_index = (P.H - y - 1) * P.W + x;
-    return in_task && x >= 0 && y >= 0 && x < P.W && y < P.H;
-}
 
 // kWalk: 0 = per-lane two-phase walk, 1 = wave-uniform walk with a 64-bit path mask (<= 64 inner
 // nodes), 2 = wave-uniform walk with the per-lane LDS stack (medium trees), 3 = SAH tree walk.

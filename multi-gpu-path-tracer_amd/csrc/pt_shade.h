@@ -1,0 +1,312 @@
+// pt_shade.h -- device code of the integrator around one ray segment: LDS staging of the scene
+// and shading tables, per-lane path state, sample start, shading of a hit (camera::ray_color,
+// camera.h:49-83), pixel quantisation and the pixel <-> lane map.  Included by pt_device.hip only.
+#pragma once
+
+#include "pt_walk.h"
+
+namespace pt {
+namespace dev {
+
+// BaseColorTexture::value + pixel_data, Texture.h:30-69.  The reference reads row `height`
+// (one past the end) when j == 0; that row is clamped to height-1 here.
+__device__ __forceinline__ v3 tex_value(const RenderParams &P, int tex, float u, float v)
+{
+    TexDesc td = P.texs[tex];
+    if (td.h <= 0) return mk3((float)242 / 255, (float)45 / 255, (float)27 / 255);
+    u = fmodf(u, 1.0f); v = fmodf(v, 1.0f);
+    int i = (int)(u * (float)td.w);
+    int j = (int)(v * (float)td.h);
+    int x = i < 0 ? 0 : (i < td.w ? i : td.w - 1);
+    int y = j < 0 ? 0 : (j < td.h ? j : td.h - 1);
+    y = td.h - y;
+    if (y > td.h - 1) y = td.h - 1;
+    const float *px = P.texels + td.offset + 3 * ((size_t)y * (size_t)td.w + (size_t)x);
+    double cs = 1.0 / 255.0;
+    return mk3((float)(cs * (double)px[0]), (float)(cs * (double)px[1]), (float)(cs * (double)px[2]));
+}
+
+struct Onb { v3 a0, a1, a2; };
+// onb::onb, onb.h:8-13
+__device__ __forceinline__ Onb onb_make(v3 n)
+{
+    Onb b;
+    b.a2 = normalize(n);
+    v3 a = fabsf(b.a2.x) > 0.9f ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
+    b.a1 = normalize(cross(b.a2, a));
+    b.a0 = cross(b.a2, b.a1);
+    return b;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Dynamic LDS layout of a workgroup: [staged NodePairs][staged TriIsects] (only when the scene
+// is staged) [traversal stacks: stack_entries x blockDim dwords][leaf queues: queue_entries x
+// blockDim uint2].  All sections are 16-byte aligned.
+struct LdsLayout {
+    const float4 *nodes;
+    const float4 *tris;
+    uint32_t *stack;
+    void *queue;
+    float4 *tail;             // first float4 after the traversal sections (shading tables)
+};
+
+template <bool kLds>
+__device__ __forceinline__ LdsLayout lds_carve(const RenderParams &P, float4 *base, int block)
+{
+    LdsLayout L;
+    size_t off = 0;                                  // in float4 units
+    L.nodes = base;
+    if (kLds) off += (size_t)P.n_pairs * 4;
+    L.tris = base + off;
+    if (kLds) off += (size_t)P.n_tris * 3;
+    L.stack = reinterpret_cast<uint32_t *>(base + off);
+    off += ((size_t)P.stack_entries * block + 3) / 4;
+    L.queue = reinterpret_cast<void *>(base + off);
+    off += ((size_t)P.queue_entries * block * P.queue_dwords + 3) / 4;
+    L.tail = base + off;
+    return L;
+}
+
+// Cooperative copy of the node and triangle arrays into LDS (scene fits: Cornell box 2.4 KB).
+template <bool kLds>
+__device__ __forceinline__ SceneView<kLds> stage_scene(const RenderParams &P, float4 *base, int tid, int block)
+{
+    SceneView<kLds> S;
+    if (kLds) {
+        const float4 *gn = reinterpret_cast<const float4 *>(P.nodes);
+        const float4 *gt = reinterpret_cast<const float4 *>(P.tris);
+        const int nn = P.n_pairs * 4, nt = P.n_tris * 3;
+        for (int i = tid; i < nn; i += block) base[i] = gn[i];
+        for (int i = tid; i < nt; i += block) base[nn + i] = gt[i];
+        __syncthreads();
+        S.nodes = base;
+        S.tris = base + nn;
+    } else {
+        S.nodes = reinterpret_cast<const float4 *>(P.nodes);
+        S.tris = reinterpret_cast<const float4 *>(P.tris);
+    }
+    return S;
+}
+
+// Shading tables (TriShade per slot, MatRec, LightRec).  Fetching them from HBM/L2 costs a chain
+// of three dependent loads per hit; small scenes keep them in LDS after the traversal sections.
+struct ShadeView {
+    const float4 *shade;      // 3 x float4 per slot
+    const float4 *mats;       // 3 x float4 per material
+    const float4 *lights;     // 5 x float4 per light
+};
+
+__device__ __forceinline__ ShadeView stage_shade(const RenderParams &P, float4 *lds, int tid, int block)
+{
+    ShadeView V;
+    if (P.shade_lds) {
+        const float4 *gs = reinterpret_cast<const float4 *>(P.shade);
+        const float4 *gm = reinterpret_cast<const float4 *>(P.mats);
+        const float4 *gl = reinterpret_cast<const float4 *>(P.lights);
+        const int ns = P.n_tris * 3, nm = P.n_mats * 3, nl = P.n_lights * 5;
+        for (int i = tid; i < ns; i += block) lds[i] = gs[i];
+        for (int i = tid; i < nm; i += block) lds[ns + i] = gm[i];
+        for (int i = tid; i < nl; i += block) lds[ns + nm + i] = gl[i];
+        __syncthreads();
+        V.shade = lds; V.mats = lds + ns; V.lights = lds + ns + nm;
+    } else {
+        V.shade = reinterpret_cast<const float4 *>(P.shade);
+        V.mats = reinterpret_cast<const float4 *>(P.mats);
+        V.lights = reinterpret_cast<const float4 *>(P.lights);
+    }
+    return V;
+}
+
+// render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
+// camera::ray_color (camera.h:49-83) flattened into a per-lane state machine.
+// Per-lane integrator state of camera::ray_color (camera.h:49-83) and of render's sample loop
+// (DevicePathTracer.h:80-87), plus this lane's exact work counters.
+struct PathState {
+    xorwow rng;
+    v3 col, atten, ro, rd;
+    int s;                 // samples started
+    unsigned bounce;       // segments traced on the current path
+    bool need_new;         // the next trip starts a new sample
+    uint32_t n_paths, n_seg, n_box, n_tri, n_light;
+};
+
+__device__ __forceinline__ void path_init(PathState &L, const RenderParams &P, int pixel_index)
+{
+    xorwow_init(L.rng, (uint64_t)(long long)(1984 + pixel_index));   // :54 seed, :80 state copy
+    L.col = mk3(0.0f, 0.0f, 0.0f);
+    L.atten = mk3(1.0f, 1.0f, 1.0f);
+    L.ro = P.cam.origin; L.rd = mk3(0.0f, 0.0f, 0.0f);
+    L.s = 0; L.bounce = 0; L.need_new = true;
+    L.n_paths = L.n_seg = L.n_box = L.n_tri = L.n_light = 0;
+}
+
+// Starts the next sample of pixel (x, y): DevicePathTracer.h:84-86 + camera::get_ray camera.h:95-97.
+// Returns false when all samples are done.
+__device__ __forceinline__ bool start_path(PathState &L, const RenderParams &P, int x, int y)
+{
+    if (L.s >= P.spp) return false;
+    float u = ((float)x + xorwow_uniform(L.rng)) / (float)(unsigned)P.W;
+    float v = ((float)y + xorwow_uniform(L.rng)) / (float)(unsigned)P.H;
+    L.ro = P.cam.origin;
+    L.rd = ((P.cam.llc + u * P.cam.horizontal) + v * P.cam.vertical) - P.cam.origin;
+    L.atten = mk3(1.0f, 1.0f, 1.0f);
+    L.bounce = 0;
+    L.s++;
+    L.n_paths++;
+    L.need_new = false;
+    return true;
+}
+
+// What camera::ray_color does with the result of one BVH::hit (camera.h:55-80): miss, emissive
+// hit, or a scattering bounce that sets up the next ray segment.
+__device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const ShadeView &V, const Hit &h)
+{
+    if (h.slot < 0) {
+        L.col = L.col + mk3(0.0f, 0.0f, 0.0f) * L.atten;                // camera.h:78-79
+        L.need_new = true;
+        return;
+    }
+    // hit_record completion, triangle.h:100-108
+    const float4 tc = V.shade[3 * (size_t)h.slot + 2];
+    v3 normal = mk3(tc.x, tc.y, tc.z);
+    v3 p = L.ro + h.t * L.rd;
+    const float4 *sp4 = V.shade + 3 * (size_t)h.slot;
+    float4 s0 = sp4[0], s1 = sp4[1];
+    int mat = __float_as_int(s1.z);
+    const float4 *mp = V.mats + 3 * (size_t)mat;
+    float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+    int baseTex = __float_as_int(m0.w), emisTex = __float_as_int(m1.w);
+    float tu = 0.0f, tv = 0.0f;
+    if (baseTex >= 0 || emisTex >= 0) {
+        tu = (1 - h.u - h.v) * s0.x + h.u * s0.z + h.v * s1.x;
+        tv = (1 - h.u - h.v) * s0.y + h.u * s0.w + h.v * s1.y;
+    }
+    // UniversalMaterial::emitted, material.h:80-86
+    v3 emitted = mk3(m2.x, m2.y, m2.z);
+    if (emisTex >= 0) emitted = (tex_value(P, emisTex, tu, tv) * mk3(m1.x, m1.y, m1.z)) * 50.0f;
+    if (emitted.x > 0.0001f || emitted.y > 0.0001f || emitted.z > 0.0001f) {   // material.h:63
+        L.col = L.col + L.atten * emitted;                               // camera.h:72-74
+        L.need_new = true;
+        return;
+    }
+    // material.h:67-68: a cosine sample that camera.h:65 overwrites; its 2 draws remain.
+    (void)xorwow_next(L.rng); (void)xorwow_next(L.rng);
+    v3 albedo = mk3(m0.x, m0.y, m0.z);
+    if (baseTex >= 0) albedo = albedo * tex_value(P, baseTex, tu, tv);
+    Onb uvw = onb_make(normal);                                    // cosine_pdf ctor, pdf.h:15-17
+    v3 dir;
+    if (xorwow_uniform(L.rng) < 0.5f) {                              // mixture_pdf::generate, pdf.h:66-72
+        float uu = xorwow_uniform(L.rng);                            // hitable_list::random, hitable_list.h:23-26
+        int idx = (int)truncf((float)((double)uu * P.light_index_scale));
+        const float4 *lp = V.lights + 5 * (size_t)idx;
+        float4 la = lp[0], ld = lp[3], le = lp[4];
+        float r1 = xorwow_uniform(L.rng), r2 = xorwow_uniform(L.rng);  // triangle::random, triangle.h:41-47
+        float sq = sqrtf(r1);
+        v3 lv0 = mk3(la.x, la.y, la.z), lv1 = mk3(ld.x, ld.y, ld.z), lv2 = mk3(ld.w, le.x, le.y);
+        v3 rp = ((1 - sq) * lv0 + (sq * (1 - r2)) * lv1) + (sq * r2) * lv2;
+        dir = rp - p;
+    } else {
+        float r1 = xorwow_uniform(L.rng), r2 = xorwow_uniform(L.rng);  // random_cosine_direction, helper_math.h:1519-1527
+        float z = sqrtf(1 - r2);
+        float phi = (float)(2 * M_PI * (double)r1);
+        float sn, cs;
+        pt_sincosf(phi, sn, cs);
+        float sq2 = sqrtf(r2);
+        float lx = cs * 2 * sq2, ly = sn * 2 * sq2;
+        dir = (lx * uvw.a0 + ly * uvw.a1) + z * uvw.a2;            // onb::local, onb.h:20-22
+    }
+    // hitable_list::pdf_value, hitable_list.h:16-22 -> triangle::pdf_value, triangle.h:32-40
+    float lsum = 0.0f;
+    for (int k = 0; k < P.n_lights; k++) {
+        const float4 *lp = V.lights + 5 * (size_t)k;
+        float4 la = lp[0], lb = lp[1], lc = lp[2], le = lp[4];
+        v3 v0 = mk3(la.x, la.y, la.z), e1 = mk3(la.w, lb.x, lb.y), e2 = mk3(lb.z, lb.w, lc.x);
+        v3 ln = mk3(lc.y, lc.z, lc.w);
+        float t, u, v;
+        L.n_light++;
+        float pdfv = 0.0f;
+        if (tri_hit(v0, e1, e2, p, dir, 0.001f, 3.402823466e+38f, t, u, v)) {
+            float distance_squared = t * t * dot(dir, dir);
+            float cosine = fabsf(dot(dir, ln) / length(dir));
+            pdfv = distance_squared / (cosine * le.z);
+        }
+        lsum += P.light_weight * pdfv;
+    }
+    v3 ndir = normalize(dir);
+    float cosv = dot(ndir, uvw.a2);                                // cosine_pdf::value, pdf.h:19-22
+    float cpdf = (cosv <= 0) ? 0.0f : (float)((double)cosv / M_PI);
+    float pdf_value = 0.5f * lsum + 0.5f * cpdf;                   // mixture_pdf::value, pdf.h:63-65
+    float cos2 = dot(normal, ndir);                                // scattering_pdf, material.h:88-91
+    float spdf = cos2 < 0 ? 0.0f : (float)((double)cos2 / M_PI);
+    L.atten = L.atten * ((albedo * spdf) / pdf_value);                 // camera.h:69
+    L.ro = p; L.rd = dir;
+    L.bounce++;
+    if (L.bounce >= P.depth) {
+        L.col = L.col + mk3(0.0f, 0.0f, 0.0f);                         // camera.h:82
+        L.need_new = true;
+    }
+}
+
+// Quantisation + RGB / YUV420 store of one pixel, DevicePathTracer.h:98-119.
+__device__ __forceinline__ void write_pixel(const RenderParams &P, v3 col, int pixel_index)
+{
+{
+    // :98-119
+    v3 q = (255.99f * col) / (float)P.spp;
+    int cr = f2i_rz_sat(q.x * 1.0f), cg = f2i_rz_sat(q.y * 1.0f), cb = f2i_rz_sat(q.z * 1.0f);
+    cr = min(255, cr); cg = min(255, cg); cb = min(255, cb);
+    P.rgb[3 * (size_t)pixel_index] = (uint8_t)cr;
+    P.rgb[3 * (size_t)pixel_index + 1] = (uint8_t)cg;
+    P.rgb[3 * (size_t)pixel_index + 2] = (uint8_t)cb;
+    P.yuv[pixel_index] = (uint8_t)(((66 * cr + 129 * cg + 25 * cb + 128) >> 8) + 16);
+    int blockRow = pixel_index / P.W, blockCol = pixel_index % P.W;
+    if (blockRow % 2 == 0 && blockCol % 2 == 0) {
+        int total = P.W * P.H, uvSize = total / 4;
+        int uvIndex = (blockRow / 2) * (P.W / 2) + (blockCol / 2);
+        P.yuv[total + uvIndex] = (uint8_t)(((-38 * cr - 74 * cg + 112 * cb + 128) >> 8) + 128);
+        P.yuv[total + uvSize + uvIndex] = (uint8_t)(((112 * cr - 94 * cg - 18 * cb + 128) >> 8) + 128);
+    }
+}
+}
+
+// Exact work counters: one atomic per wave per counter.
+__device__ __forceinline__ void flush_counters(const RenderParams &P, const PathState &L, int lane)
+{
+    uint32_t c0 = wave_sum(L.n_paths), c1 = wave_sum(L.n_seg), c2 = wave_sum(L.n_box), c3 = wave_sum(L.n_tri),
+             c4 = wave_sum(L.n_light);
+    if (lane == 0 && (c0 | c1)) {
+        atomicAdd(&P.counters[0], (unsigned long long)c0);
+        atomicAdd(&P.counters[1], (unsigned long long)c1);
+        atomicAdd(&P.counters[2], (unsigned long long)c2);
+        atomicAdd(&P.counters[3], (unsigned long long)c3);
+        atomicAdd(&P.counters[4], (unsigned long long)c4);
+    }
+}
+
+// Pixel of this lane: 8x8 tile per wave; in row-band mode (pt_render_bands_async) local row j is row
+// (j % band_rows) of this rank's (j / band_rows)-th band, band b of the frame (fb rows, 0 = top)
+// belonging to rank b % band_ranks.
+__device__ __forceinline__ bool lane_pixel(const RenderParams &P, int tid, int &x, int &y, int &pixel_index)
+{
+    const int lane = tid & (kWave - 1);
+    const int wave = tid / kWave;
+    const int tile = blockIdx.x * kWavesPerBlock + wave;
+    const int tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
+    const int i = tile_x * 8 + (lane & 7), j = tile_y * 8 + (lane >> 3);
+    const bool in_task = (tile_y < P.tiles_y) && (i < P.task_w) && (j < P.task_h);
+    x = P.task_ox + i; y = P.task_oy + j;
+    if (P.band_ranks > 0) {
+        const int fb_row = ((j / P.band_rows) * P.band_ranks + P.band_rank) * P.band_rows + (j % P.band_rows);
+        y = P.H - 1 - fb_row;
+    }
+    pixel_index = (P.H - y - 1) * P.W + x;
+    return in_task && x >= 0 && y >= 0 && x < P.W && y < P.H;
+}
+
+} // namespace dev
+} // namespace pt

@@ -1,0 +1,395 @@
+// pt_walk.h -- device code of the ray / scene intersection: slab and Moller-Trumbore tests and
+// the four traversal schedules of the render kernel.  Included by
+// pt_device.hip only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "pt_kernels.h"
+
+namespace pt {
+namespace dev {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+
+struct Hit {
+    float t, u, v;
+    int slot;          // leaf-order triangle slot of the closest hit, -1 = none
+};
+
+// aabb::hit, aabb.h:38-66 (ray_t / rec ignored there too).  inv = 1.0f / direction.
+__device__ __forceinline__ bool box_hit(float xmin, float xmax, float ymin, float ymax, float zmin,
+                                        float zmax, v3 o, v3 inv)
+{
+    float t1 = (xmin - o.x) * inv.x, t2 = (xmax - o.x) * inv.x;
+    float t3 = (ymin - o.y) * inv.y, t4 = (ymax - o.y) * inv.y;
+    float t5 = (zmin - o.z) * inv.z, t6 = (zmax - o.z) * inv.z;
+    float tmin = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    float tmax = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    return !(tmax < 0) && !(tmin > tmax);
+}
+
+// triangle::hit, triangle.h:63-113 (Moller-Trumbore) on a precomputed (v0, e1, e2) record.
+// Returns true when the candidate is accepted for the interval (tmin, tmax); t/u/v out.
+__device__ __forceinline__ bool tri_hit(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float tmin, float tmax,
+                                        float &t_out, float &u_out, float &v_out)
+{
+    v3 pvec = cross(d, e2);
+    float det = dot(e1, pvec);
+    // triangle.h:78 compares in double against +-1e-8; for a float det that is exactly
+    // |det| <= 1e-8f (1e-8f < 1e-8 < nextafter(1e-8f)).
+    bool ok = !(det <= 1e-8f && det >= -1e-8f);
+    float inv_det = 1.0f / det;                       // :84 (double divide == IEEE 1.0f/det)
+    v3 tvec = o - v0;
+    float u = dot(tvec, pvec) * inv_det;
+    ok = ok && !(u < 0 || u > 1);
+    v3 qvec = cross(tvec, e1);
+    float v = dot(d, qvec) * inv_det;
+    ok = ok && !(v < 0 || u + v > 1);
+    float t = dot(e2, qvec) * inv_det;
+    ok = ok && (t < tmax && t > tmin);
+    t_out = t; u_out = u; v_out = v;
+    return ok;
+}
+
+// Moller-Trumbore arithmetic of triangle.h:63-98 without the interval test: the u/v/t values and
+// whether det, u and v pass (same operations, same order as tri_hit).
+__device__ __forceinline__ bool mt_eval(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float &t, float &u, float &v)
+{
+    v3 pvec = cross(d, e2);
+    float det = dot(e1, pvec);
+    bool ok = !((det <= 1e-8f) & (det >= -1e-8f));
+    float inv_det = 1.0f / det;
+    v3 tvec = o - v0;
+    u = dot(tvec, pvec) * inv_det;
+    ok = ok & !((u < 0) | (u > 1));
+    v3 qvec = cross(tvec, e1);
+    v = dot(d, qvec) * inv_det;
+    ok = ok & !((v < 0) | (u + v > 1));
+    t = dot(e2, qvec) * inv_det;
+    return ok;
+}
+
+__device__ __forceinline__ void load_tri(const TriIsect *tris, int slot, v3 &v0, v3 &e1, v3 &e2)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(tris + slot);
+    float4 a = p[0], b = p[1], c = p[2];
+    v0 = mk3(a.x, a.y, a.z);
+    e1 = mk3(a.w, b.x, b.y);
+    e2 = mk3(b.z, b.w, c.x);
+}
+
+// Scene accessors: the node and triangle arrays are read either from HBM (through L1/L2) or,
+// when the launch staged them, from LDS (ds_read_b128).
+template <bool kLds>
+struct SceneView {
+    const float4 *nodes;      // NodePair records, 4 x float4 each
+    const float4 *tris;       // TriIsect records, 3 x float4 each
+};
+
+// BVH::hit, bvh.h:178-246, split into two phases per ray segment:
+//   phase A  walks the boxes in the reference's order (both children's boxes per visit,
+//            left-first descent, right sibling pushed on the per-lane LDS stack) and only
+//            RECORDS the leaves it would test, in visit order, in a per-lane LDS queue;
+//   phase B  runs Moller-Trumbore over the queued leaves in that same order.
+// This is the reference's exact sequence of triangle tests (aabb::hit ignores ray_t, so the
+// boxes never depend on earlier triangle results); it only keeps the lanes of a wave in the
+// same code at the same time.  When a lane's queue is full the wave drains (phase B) and
+// resumes phase A where it stopped.
+// `stack` / `queue` are this lane's LDS columns (element stride = `stride` lanes).
+// Leaf-queue entry: {first slot, triangle count}.  Scenes with < 65536 triangles pack it into
+// one dword (half the LDS), larger scenes use two.
+template <bool kPacked> struct QueueEntry;
+template <> struct QueueEntry<true> {
+    typedef uint32_t type;
+    static __device__ __forceinline__ type make(uint32_t first, uint32_t count) { return first | (count << 16); }
+    static __device__ __forceinline__ void split(type e, uint32_t &first, uint32_t &count) { first = e & 0xFFFFu; count = e >> 16; }
+};
+template <> struct QueueEntry<false> {
+    typedef uint2 type;
+    static __device__ __forceinline__ type make(uint32_t first, uint32_t count) { return make_uint2(first, count); }
+    static __device__ __forceinline__ void split(type e, uint32_t &first, uint32_t &count) { first = e.x; count = e.y; }
+};
+
+template <bool kLds, bool kPacked>
+__device__ __forceinline__ Hit traverse(const SceneView<kLds> S, v3 o, v3 d, float tmin, float tmax0,
+                                        uint32_t *stack, typename QueueEntry<kPacked>::type *queue, int stride,
+                                        int qcap, uint32_t &n_box, uint32_t &n_tri)
+{
+    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+    float tmax = tmax0;
+    v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t pair = 0;
+    int sp = 0;
+    bool walking = true;
+    while (walking) {
+        // ---------------- phase A: boxes -> leaf queue
+        int qn = 0;
+        while (walking && qn + 2 <= qcap) {
+            const float4 *np = S.nodes + 4 * (size_t)pair;
+            float4 a = np[0], b = np[1], c = np[2];
+            float4 lf = np[3];
+            uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
+            uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
+            bool ol = box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
+            bool orr = box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
+            n_box += 2;
+            if (ol && lcnt) { queue[qn * stride] = QueueEntry<kPacked>::make(llink, lcnt); qn++; }
+            if (orr && rcnt) { queue[qn * stride] = QueueEntry<kPacked>::make(rlink, rcnt); qn++; }
+            bool tl = ol && lcnt == 0, tr = orr && rcnt == 0;
+            if (tl && tr) {
+                stack[sp * stride] = rlink;
+                sp++;
+                pair = llink;
+            } else if (tl) {
+                pair = llink;
+            } else if (tr) {
+                pair = rlink;
+            } else if (sp == 0) {
+                walking = false;
+            } else {
+                sp--;
+                pair = stack[sp * stride];
+            }
+        }
+        // ---------------- phase B: triangles of the queued leaves, in queue order
+        int qi = 0;
+        uint32_t k = 0, n = 0;
+        while (true) {
+            if (n == 0) {
+                if (qi == qn) break;
+                QueueEntry<kPacked>::split(queue[qi * stride], k, n);
+                qi++;
+            }
+            const float4 *tp = S.tris + 3 * (size_t)k;
+            float4 ta = tp[0], tb = tp[1];
+            float e2z = reinterpret_cast<const float *>(tp + 2)[0];
+            float t, u, v;
+            n_tri++;
+            if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
+                tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k;
+            }
+            k++; n--;
+        }
+    }
+    return h;
+}
+
+// Wave-uniform traversal for scenes whose whole tree is at most 64 inner nodes (Cornell box:
+// 10).  All lanes of the wave walk the SAME node / triangle at the same time, in the
+// reference's visit order (NodePairs are numbered in DFS pre-order = visit order), each lane
+// carrying a 64-bit "this pair is on my path" mask instead of a stack.  Because the loop
+// counters are wave-uniform, node and triangle records arrive through the scalar cache
+// (s_load) and sit in SGPRs as instruction operands: no LDS, no per-lane queue, no divergent
+// loop trip counts.  A pair (or a leaf) that no lane of the wave reaches is skipped with one
+// scalar branch.  Per lane the sequence of slab and triangle tests is exactly bvh.h:178-246.
+__device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
+                                                uint32_t &n_box, uint32_t &n_tri)
+{
+    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+    float tmax = tmax0;
+    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
+    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
+    unsigned long long act = 1ull;                       // bit p: pair p is on this lane's path
+    const int n_pairs = P.n_pairs;
+    for (int p = 0; p < n_pairs; p++) {
+        const bool on = (act >> p) & 1ull;
+        if (__ballot(on) == 0ull) continue;              // nobody in the wave visits pair p
+        const float4 a = nodes[4 * p], b = nodes[4 * p + 1], c = nodes[4 * p + 2], lf = nodes[4 * p + 3];
+        const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
+        const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
+        const bool hl = on && box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
+        const bool hr = on && box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
+        if (on) n_box += 2;
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const bool hit = side ? hr : hl;
+            const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
+            if (cnt == 0) {                              // inner child: mark its pair
+                if (hit) act |= 1ull << link;
+            } else if (__ballot(hit) != 0ull) {          // leaf child somebody hits
+                for (uint32_t k = link; k < link + cnt; k++) {
+                    const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
+                    const float e2z = reinterpret_cast<const float *>(tris + 3 * k + 2)[0];
+                    if (hit) {
+                        float t, u, v;
+                        n_tri++;
+                        if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
+                            tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return h;
+}
+
+// The same wave-uniform walk for bigger trees (cornell_duck: 332 inner nodes, leaves of up to
+// 1603 triangles): instead of a 64-bit mask each lane keeps the NEXT pair on its path plus its
+// pending right siblings on the per-lane LDS stack.  Pairs are numbered in visit order, so the
+// pending set is a stack and `next` is always its minimum; the wave scans p upward and a lane
+// takes part in pair p iff next == p.  Leaves are tested in lockstep by every lane that hit
+// their box, with triangle records coming through the scalar cache -- a 1603-triangle leaf costs
+// 1603 uniform trips instead of 1603 divergent gather trips per lane.  Cost per ray segment is
+// the UNION of the lanes' paths, so the host picks this walk only for small / medium trees.
+__device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
+                                                      uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
+{
+    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+    float tmax = tmax0;
+    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
+    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
+    uint32_t next = 0;
+    int sp = 0;
+    bool walking = true;
+    const int n_pairs = P.n_pairs;
+    for (int p = 0; p < n_pairs; p++) {
+        const bool on = walking && next == (uint32_t)p;
+        if (__ballot(on) == 0ull) {
+            if (__ballot(walking) == 0ull) break;        // every lane of the wave is done
+            continue;
+        }
+        const float4 a = nodes[4 * p], b = nodes[4 * p + 1], c = nodes[4 * p + 2], lf = nodes[4 * p + 3];
+        const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
+        const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
+        const bool hl = on && box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
+        const bool hr = on && box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
+        if (on) {
+            n_box += 2;
+            const bool tl = hl && lcnt == 0, tr = hr && rcnt == 0;
+            if (tl && tr) {
+                stack[sp * stride] = rlink;
+                sp++;
+                next = llink;
+            } else if (tl || tr) {
+                next = tl ? llink : rlink;
+            } else if (sp == 0) {
+                walking = false;
+            } else {
+                sp--;
+                next = stack[sp * stride];
+            }
+        }
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const bool hit = side ? hr : hl;
+            const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
+            if (cnt != 0 && __ballot(hit) != 0ull) {
+                for (uint32_t k = link; k < link + cnt; k++) {
+                    const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
+                    const float e2z = reinterpret_cast<const float *>(tris + 3 * k + 2)[0];
+                    if (hit) {
+                        float t, u, v;
+                        n_tri++;
+                        if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
+                            tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return h;
+}
+
+// Opt-in walk over the SAH tree (pt_set_bvh_mode(dev, 1); not the reference's traversal): per-lane
+// LDS stack, nearer child first, subtrees whose (epsilon-inflated) box starts beyond the closest
+// hit so far are pruned.  Triangles are tested with the same Moller-Trumbore arithmetic and the
+// closest hit is min over (t, rank) -- rank = the triangle's position in the reference's visit
+// order -- which is what the reference's in-order `t < ray_t.max` update computes over the
+// triangles it tests.  Differences from the reference are confined to rays for which the two
+// traversals test different triangles AND such a triangle wins.
+struct SahWalk {
+    uint32_t pair;
+    int sp;
+    float tbest;
+    uint32_t best_rank;
+    v3 inv;
+    Hit h;
+};
+
+__device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
+{
+    W.pair = 0; W.sp = 0; W.tbest = tmax0; W.best_rank = 0xFFFFFFFFu;
+    W.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    W.h.t = 0.0f; W.h.u = 0.0f; W.h.v = 0.0f; W.h.slot = -1;
+}
+
+// One node visit of the SAH walk (both child boxes, the triangles of hit leaf children, then
+// descend / pop).  Returns false when the walk is complete.
+__device__ __forceinline__ bool sah_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin,
+                                         uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
+{
+    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
+    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
+    const float4 *np = nodes + 4 * (size_t)W.pair;
+    const float4 a = np[0], b = np[1], c = np[2], lf = np[3];
+    const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
+    const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
+    const v3 inv = W.inv;
+    float tnl, tnr;
+    bool hl, hr;
+    {
+        float t1 = (a.x - o.x) * inv.x, t2 = (a.y - o.x) * inv.x, t3 = (a.z - o.y) * inv.y, t4 = (a.w - o.y) * inv.y;
+        float t5 = (b.x - o.z) * inv.z, t6 = (b.y - o.z) * inv.z;
+        tnl = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+        float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+        hl = (tf >= fmaxf(tnl, 0.0f)) & (tnl <= W.tbest);
+    }
+    {
+        float t1 = (b.z - o.x) * inv.x, t2 = (b.w - o.x) * inv.x, t3 = (c.x - o.y) * inv.y, t4 = (c.y - o.y) * inv.y;
+        float t5 = (c.z - o.z) * inv.z, t6 = (c.w - o.z) * inv.z;
+        tnr = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+        float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+        hr = (tf >= fmaxf(tnr, 0.0f)) & (tnr <= W.tbest);
+    }
+    n_box += 2;
+    // leaf children: one Moller-Trumbore loop over both ranges
+    uint32_t k0 = llink, n0 = (hl && lcnt) ? lcnt : 0u;
+    uint32_t k1 = rlink, n1 = (hr && rcnt) ? rcnt : 0u;
+    if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
+    while (n0 != 0) {
+        const float4 *tp = tris + 3 * (size_t)k0;
+        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+        float t, u, v;
+        n_tri++;
+        const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d, t, u, v);
+        const uint32_t rank = __float_as_uint(tc.y);
+        if (ok & (t > tmin) & ((t < W.tbest) | ((t == W.tbest) & (rank < W.best_rank)))) {
+            W.tbest = t; W.best_rank = rank; W.h.t = t; W.h.u = u; W.h.v = v; W.h.slot = (int)k0;
+        }
+        k0++; n0--;
+        if (n0 == 0) { k0 = k1; n0 = n1; n1 = 0; }
+    }
+    const bool gl = hl && lcnt == 0 && tnl <= W.tbest, gr = hr && rcnt == 0 && tnr <= W.tbest;
+    if (gl && gr) {
+        const bool left_first = tnl <= tnr;
+        stack[W.sp * stride] = left_first ? rlink : llink;
+        W.sp++;
+        W.pair = left_first ? llink : rlink;
+    } else if (gl || gr) {
+        W.pair = gl ? llink : rlink;
+    } else {
+        if (W.sp == 0) return false;
+        W.sp--;
+        W.pair = stack[W.sp * stride];
+    }
+    return true;
+}
+
+__device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
+                                            uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
+{
+    SahWalk W;
+    sah_begin(W, d, tmax0);
+    while (sah_step(P, W, o, d, tmin, stack, stride, n_box, n_tri)) {}
+    return W.h;
+}
+
+} // namespace dev
+} // namespace pt
