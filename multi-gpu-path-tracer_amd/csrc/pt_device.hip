@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P)
         while (true) {
             if (walking) walking = sah_step(P, W, L.ro, L.rd, 0.001f, stack, kBlock, L.n_box, L.n_tri);
             const int still = __popcll(__ballot(walking));
-            if (still * 2 <= total) break;
+            if (still * 100 <= total * P.spec_pct) break;
         }
         if (alive && !walking) shade(L, P, V, W.h);
     }
@@ -253,6 +253,7 @@ struct pt_device {
     int walk = 0;                 // traversal schedule: 0 per-lane, 1 uniform/mask, 2 uniform/stack, 3 SAH tree
     bool sah = false;             // uploaded with the opt-in SAH tree instead of the reference topology
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
+    int spec_pct = 65;            // ... and leaves the walk loop when <= this % of the walkers remain
     int bvh_mode = 0;             // pt_set_bvh_mode: applies to the next pt_upload_scene
     int force_walk = -1;          // pt_set_traversal_mode: -1 auto, else the requested schedule
     int queue_entries = 8;        // per-lane leaf queue capacity (phase A -> phase B)
@@ -327,7 +328,8 @@ pt_status pt_device_create(int device_index, pt_device **out)
     PT_HIP(hipSetDevice(device_index));
     std::unique_ptr<pt_device> d(new pt_device());
     d->index = device_index;
-    if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;      // diagnostic A/B switch
+    if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;      // diagnostic A/B switches
+    if (getenv("PTAMD_SPEC_PCT")) d->spec_pct = atoi(getenv("PTAMD_SPEC_PCT"));
     PT_HIP(hipMalloc((void **)&d->d_counters, 8 * sizeof(unsigned long long)));
     PT_HIP(hipMemset(d->d_counters, 0, 8 * sizeof(unsigned long long)));
     *out = d.release();
@@ -623,6 +625,7 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.n_tris = (int)dev->n_tris;
     P.queue_entries = dev->queue_entries;
     P.sah = dev->sah ? 1 : 0;
+    P.spec_pct = dev->spec_pct;
     if (dev->sah) P.stack_entries = (int)dev->sah_stack;
     P.queue_dwords = dev->packed_queue ? 1 : 2;
     P.n_mats = (int)dev->n_mats;

@@ -37,6 +37,7 @@ struct RenderParams {
     int queue_dwords;                 // dwords per queue entry (1 packed, 2 otherwise)
     int n_pairs, n_tris;              // array lengths (for LDS staging)
     int n_mats;                       // material records
+    int spec_pct;                     // SAH kernel: leave the walk loop when <= this % of the walkers remain
     int sah;                          // 1: nodes/tris hold the opt-in SAH tree (traverse_sah)
     int shade_lds;                    // 1: shade / material / light tables are staged in LDS
 };

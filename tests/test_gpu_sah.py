@@ -86,3 +86,23 @@ def test_sah_handles_tiny_and_terrain_scenes(pt, ob, gpu_device):
     tr.renderTaskAsync(pt.RenderTask(16, 16, 0, 0)); tr.waitForRenderTask()
     assert np.array_equal(fb.rgb_host(), ref[0])
     tr.close()
+
+
+@pytest.mark.parametrize("name,W,H,spp", [("box", 480, 270, 64), ("duck", 320, 180, 32), ("box", 1920, 1080, 256)])
+def test_sah_vs_reference_tree_at_scale(pt, box_scene, duck_scene, gpu_device, name, W, H, spp):
+    """Frames too big for the CPU oracle: render the same frame through the reference-topology walk
+    (bit-exact with the oracle by test_gpu_parity) and through the SAH tree, count differing bytes."""
+    scene, cam = (box_scene, BOX_CAMERA) if name == "box" else (duck_scene, DUCK_CAMERA)
+    ref_tr, ref_fb = _tracer(pt, scene, cam, W, H, spp, 8, sah=False)
+    ref_tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); ref_tr.waitForRenderTask()
+    ref = ref_fb.rgb_host().copy(); ref_cnt = ref_tr.readCounters(); ref_tr.close()
+    sah_tr, sah_fb = _tracer(pt, scene, cam, W, H, spp, 8, sah=True)
+    sah_tr.resetCounters()
+    sah_tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); sah_tr.waitForRenderTask()
+    got = sah_fb.rgb_host().copy(); cnt = sah_tr.readCounters(); sah_tr.close()
+    ndiff = int((got != ref).sum())
+    maxdiff = int(np.abs(got.astype(int) - ref.astype(int)).max())
+    print("%s %dx%d %dspp: %d of %d bytes differ (max |delta| %d); segments %d vs %d; tri tests %.3g -> %.3g"
+          % (name, W, H, spp, ndiff, got.size, maxdiff, cnt["segments"], ref_cnt["segments"], ref_cnt["tri_tests"], cnt["tri_tests"]))
+    assert ndiff <= got.size * 1e-4
+    assert abs(cnt["segments"] - ref_cnt["segments"]) <= ref_cnt["segments"] * 1e-5
