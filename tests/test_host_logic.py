@@ -210,3 +210,91 @@ def test_render_without_gpu_fails_loudly(pt, box_scene):
     h = C.c_void_p()
     st = pt.capi.lib().pt_device_create(0, C.byref(h))
     assert st == 8 and b"no CPU fallback" in pt.capi.lib().pt_last_error_string()
+
+
+def _minimal_glb(json_obj, bin_bytes=b""):
+    import json as _json
+    import struct
+    js = _json.dumps(json_obj).encode()
+    js += b" " * (-len(js) % 4)
+    bin_bytes = bin_bytes + b"\x00" * (-len(bin_bytes) % 4)
+    chunks = struct.pack("<II", len(js), 0x4E4F534A) + js
+    if bin_bytes:
+        chunks += struct.pack("<II", len(bin_bytes), 0x004E4942) + bin_bytes
+    return b"glTF" + struct.pack("<II", 2, 12 + len(chunks)) + chunks
+
+
+def test_glb_loader_handcrafted_files(pt, tmp_path):
+    """Node hierarchy with nested TRS, matrix nodes, non-indexed primitives, default material,
+    negative-determinant transforms (winding flip) and malformed input (errors, not crashes)."""
+    import struct
+    pos = struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0)
+    base = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}],
+        "buffers": [{"byteLength": len(pos)}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": len(pos)}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0}}]}],
+    }
+    # child node under a translated + scaled parent; non-indexed triangle; no material -> DefaultMaterial
+    j = dict(base, nodes=[{"translation": [10, 0, 0], "scale": [2, 2, 2], "children": [1]}, {"mesh": 0, "translation": [0, 1, 0]}])
+    p = tmp_path / "a.glb"; p.write_bytes(_minimal_glb(j, pos))
+    sc = pt.SceneLoader().load(str(p))
+    t = sc.triangles[0]
+    assert t["v0"]["position"].tolist() == [10, 2, 0] and t["v1"]["position"].tolist() == [12, 2, 0] and t["v2"]["position"].tolist() == [10, 4, 0]
+    assert sc.material_names == ["DefaultMaterial"] and sc.materials["baseColor"][0].tolist() == [1, 1, 1]
+    # mirrored node (negative determinant): winding is reversed so the geometric normal stays consistent
+    j = dict(base, nodes=[{"mesh": 0, "scale": [-1, 1, 1]}])
+    p.write_bytes(_minimal_glb(j, pos))
+    t = pt.SceneLoader().load(str(p)).triangles[0]
+    assert t["v0"]["position"].tolist() == [0, 1, 0] and t["v2"]["position"].tolist() == [0, 0, 0]
+    # column-major matrix node: translate by (5, 6, 7)
+    j = dict(base, nodes=[{"mesh": 0, "matrix": [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 5, 6, 7, 1]}])
+    p.write_bytes(_minimal_glb(j, pos))
+    assert pt.SceneLoader().load(str(p)).triangles[0]["v0"]["position"].tolist() == [5, 6, 7]
+    # degenerate triangle (two identical vertices) is dropped -> no triangles -> error
+    deg = struct.pack("<9f", 0, 0, 0, 0, 0, 0, 0, 1, 0)
+    p.write_bytes(_minimal_glb(dict(base, nodes=[{"mesh": 0}]), deg))
+    with pytest.raises(RuntimeError):
+        pt.SceneLoader().load(str(p))
+    # malformed: accessor beyond the buffer, index out of range, truncated chunk, garbage JSON
+    bad = dict(base, nodes=[{"mesh": 0}]); bad["accessors"] = [{"bufferView": 0, "componentType": 5126, "count": 300, "type": "VEC3"}]
+    p.write_bytes(_minimal_glb(bad, pos))
+    with pytest.raises(RuntimeError):
+        pt.SceneLoader().load(str(p))
+    idx = struct.pack("<3H", 0, 1, 7) + b"\x00\x00"
+    bad = dict(base, nodes=[{"mesh": 0}])
+    bad["buffers"] = [{"byteLength": len(pos) + len(idx)}]
+    bad["bufferViews"] = base["bufferViews"] + [{"buffer": 0, "byteOffset": len(pos), "byteLength": 6}]
+    bad["accessors"] = base["accessors"] + [{"bufferView": 1, "componentType": 5123, "count": 3, "type": "SCALAR"}]
+    bad["meshes"] = [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1}]}]
+    p.write_bytes(_minimal_glb(bad, pos + idx))
+    with pytest.raises(RuntimeError):
+        pt.SceneLoader().load(str(p))
+    whole = _minimal_glb(dict(base, nodes=[{"mesh": 0}]), pos)
+    for cut in (10, 20, len(whole) - 5):
+        p.write_bytes(whole[:cut])
+        with pytest.raises(RuntimeError):
+            pt.SceneLoader().load(str(p))
+    p.write_bytes(b"glTF" + struct.pack("<II", 2, 40) + struct.pack("<II", 20, 0x4E4F534A) + b"{not json at all!!}}")
+    with pytest.raises(RuntimeError):
+        pt.SceneLoader().load(str(p))
+
+
+def test_capi_argument_checking(pt, box_scene):
+    """Null pointers and bad sizes come back as PT_ERR_INVALID with a message, never a crash."""
+    lib = pt.capi.lib()
+    out = C.c_void_p()
+    assert lib.pt_scene_load_glb(None, C.byref(out)) == 1 and lib.pt_last_error_string()
+    assert lib.pt_scene_make_terrain(0, C.byref(out)) == 1
+    assert lib.pt_tasks_equal_row(0, 10, 10, None) == 1
+    assert lib.pt_tasks_equal_layout(2, 0, 10, 10, None) == 1
+    n = C.c_int()
+    assert lib.pt_tasks_row_bands(10, 10, 3, 1, 0, None, 0, C.byref(n)) == 1          # odd band height
+    assert lib.pt_host_bvh_build(None, 0, None, None, None, None) == 1
+    assert lib.pt_write_ppm(b"/nonexistent-dir/x.ppm", 2, 2, pt.capi.np_ptr(np.zeros(12, np.uint8))) == 5
+    assert b"cannot write" in lib.pt_last_error_string()
+    # device entry points with a null device never touch the GPU
+    assert lib.pt_device_sync(None) == 1 and lib.pt_counters_reset(None) == 1
+    assert lib.pt_render_task_async(None, None, None, 1, 1, None) == 1
+    assert lib.pt_device_destroy(None) == 0
