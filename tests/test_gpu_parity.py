@@ -243,3 +243,51 @@ def test_c5_parameters_small_frame(pt, box_scene, box_oracle, gpu_device):
     """BASELINE.json configs[4] parameters (1024 spp, 16 bounces) on a small frame."""
     ref = box_oracle.render(BOX_CAMERA, 32, 16, 1024, 16, threads=8)
     _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, 32, 16, 1024, 16), ref)
+
+
+def _random_scene(pt, seed):
+    """Random triangle soup in [-10,10]^3 with random materials, 1-3 emissive triangles, random UVs
+    and (sometimes) a texture: nothing about it is tuned to any walk's fast path."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(6, 400)) if seed < 8 else int(rng.integers(6, 90))      # seeds >= 8: small trees (mask walk)
+    tris = np.zeros(n, pt.capi.TRIANGLE_DTYPE)
+    centre = rng.uniform(-8, 8, (n, 3)).astype(np.float32)
+    size = rng.uniform(0.3, 5.0, (n, 1, 1)).astype(np.float32)
+    verts = centre[:, None, :] + (rng.standard_normal((n, 3, 3)).astype(np.float32) * size)
+    if seed % 3 == 0:                                   # some exactly axis-aligned / coplanar geometry
+        verts[: n // 3, :, 1] = np.float32(-6.0)
+    for k, name in enumerate(("v0", "v1", "v2")):
+        tris[name]["position"] = verts[:, k, :]
+        tris[name]["texCoords"] = rng.uniform(-1.5, 2.5, (n, 2)).astype(np.float32)
+    n_mats = int(rng.integers(2, 6))
+    mats = np.zeros(n_mats, pt.capi.MATERIAL_DTYPE)
+    mats["baseColor"] = rng.uniform(0.1, 0.9, (n_mats, 3)).astype(np.float32)
+    mats["baseColorTextureIdx"] = -1; mats["emissiveTextureIdx"] = -1
+    mats[0]["emissiveFactor"] = rng.uniform(0.2, 1.0, 3).astype(np.float32)
+    texs = []
+    if seed % 2 == 0:
+        texs = [rng.integers(0, 256, (int(rng.integers(1, 9)), int(rng.integers(1, 9)), 3)).astype(np.float32)]
+        mats[n_mats - 1]["baseColorTextureIdx"] = 0
+    tris["materialIdx"] = rng.integers(1, n_mats, n)
+    lights = rng.choice(n, int(rng.integers(1, 4)), replace=False)
+    tris["materialIdx"][lights] = 0
+    for k, name in enumerate(("v0", "v1", "v2")):          # lights: big triangles around the middle
+        tris[name]["position"][lights] = (rng.standard_normal((len(lights), 3)) * 6.0).astype(np.float32)
+    eye = rng.standard_normal(3); eye = eye / np.linalg.norm(eye) * rng.uniform(14, 30)
+    front = -eye / np.linalg.norm(eye) + rng.standard_normal(3) * 0.05
+    cam = (tuple(eye.astype(np.float32).tolist()), tuple(front.astype(np.float32).tolist()),
+           float(rng.uniform(30, 90)), float(rng.uniform(30, 90)))
+    return tris, mats, texs, cam
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_scenes_bit_exact_in_every_walk(pt, ob, gpu_device, seed):
+    tris, mats, texs, cam = _random_scene(pt, seed)
+    scene = pt.HostScene.from_arrays(tris, mats, texs)
+    osc = ob.OracleScene(tris, mats, texs)
+    W, H, spp, depth = 40, 24, 3, 6
+    ref = osc.render(cam, W, H, spp, depth, threads=8)
+    info = pt.host_bvh_build(tris)[0]
+    modes = [1, 3] + ([2] if info["nodes"] - info["leaves"] <= 64 else [])
+    for mode in modes:
+        _assert_same(_render_gpu(pt, scene, cam, W, H, spp, depth, mode=mode), ref)
