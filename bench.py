@@ -51,13 +51,13 @@ def measured_traffic(config):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pmc_summary.json" % config)))
     if not files:
-        return None, None
+        return None, None, None
     try:
         with open(files[-1]) as f:
             d = json.load(f)
-        return float(d["hbm_bytes_per_launch"]["total"]), os.path.relpath(files[-1], ROOT)
+        return float(d["hbm_bytes_per_launch"]["total"]), os.path.relpath(files[-1], ROOT), d.get("valu_roofline")
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def load_scene(pt, kind):
@@ -204,9 +204,9 @@ def main():
         my_pixels = sum(t.width * t.height for t in mgr.renderTasks_) * args.steps
         bytes_rank0 = algorithmic_bytes(cnt, my_pixels)
         achieved = bytes_rank0 / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic, traffic_src = (None, None)
-        if world == 1 and not (args.width or args.height):
-            traffic, traffic_src = measured_traffic(args.config)
+        traffic, traffic_src, valu = (None, None, None)
+        if world == 1 and not (args.width or args.height) and bvh == "reference":
+            traffic, traffic_src, valu = measured_traffic(args.config)
         out = {
             "metric": "ray-segments/s", "value": seg_per_s, "unit": "ray-segments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -222,6 +222,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_rank0 / max(launches, 1),
+                "valu_roofline_from_profile": valu,
                 "note": "algorithmic bytes (SURVEY 8d) are served by the scalar cache / L1 on this KB-sized scene; "
                         "the HBM traffic of a launch is `traffic` bytes, the kernel is VALU-issue bound (DESIGN.md 4)",
                 "kernel": "pt::dev::render_kernel", "kernel_ms_avg": kernel_ms / max(launches, 1),
