@@ -298,3 +298,113 @@ def test_capi_argument_checking(pt, box_scene):
     assert lib.pt_device_sync(None) == 1 and lib.pt_counters_reset(None) == 1
     assert lib.pt_render_task_async(None, None, None, 1, 1, None) == 1
     assert lib.pt_device_destroy(None) == 0
+
+
+def _png(width, height, color_type, rows, bit_depth=8, palette=None, trns=None, filters=None):
+    """Tiny PNG writer for tests: rows = list of per-row raw sample bytes; filters = per-row filter
+    type (the row bytes are filtered here with the requested PNG filter)."""
+    import struct
+    import zlib
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    spp = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color_type]
+    bpp = max(1, spp * bit_depth // 8)
+    raw = b""
+    prev = bytes(len(rows[0]))
+    for y, row in enumerate(rows):
+        ft = filters[y] if filters else 0
+        out = bytearray()
+        for i, v in enumerate(row):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0: p = 0
+            elif ft == 1: p = a
+            elif ft == 2: p = b
+            elif ft == 3: p = (a + b) // 2
+            else:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out.append((v - p) & 0xFF)
+        raw += bytes([ft]) + bytes(out)
+        prev = row
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, bit_depth, color_type, 0, 0, 0))
+    if palette is not None:
+        data += chunk(b"PLTE", bytes(palette))
+    if trns is not None:
+        data += chunk(b"tRNS", bytes(trns))
+    half = len(raw) // 2 or 1
+    comp = zlib.compress(raw)
+    data += chunk(b"IDAT", comp[:len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:])     # split IDAT
+    return data + chunk(b"IEND", b"")
+
+
+def _glb_with_texture(png_bytes):
+    import struct
+    pos = struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0)
+    uv = struct.pack("<6f", 0, 0, 1, 0, 0, 1)
+    blob = pos + uv + png_bytes
+    j = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+        "buffers": [{"byteLength": len(blob)}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 24},
+                        {"buffer": 0, "byteOffset": 60, "byteLength": len(png_bytes)}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"},
+                      {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC2"}],
+        "images": [{"bufferView": 2, "mimeType": "image/png"}], "textures": [{"source": 0}],
+        "materials": [{"name": "m", "emissiveFactor": [1, 1, 1], "emissiveTexture": {"index": 0},
+                       "pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "baseColorFactor": [0.5, 0.25, 1, 1]}}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1}, "material": 0}]}],
+    }
+    return _minimal_glb(j, blob)
+
+
+def test_embedded_png_variants(pt, tmp_path):
+    """Embedded textures as stb_image (req_comp = 0) + the reference's 3-bytes-per-pixel copy loop
+    (HostScene.cpp:19-46) would deliver them: RGB, palette (+ every PNG filter, split IDAT), 16-bit,
+    RGBA read with the reference's wrong stride, grey refused (the reference reads out of bounds)."""
+    rng = np.random.default_rng(3)
+    p = tmp_path / "t.glb"
+    W, H = 5, 4
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    # 8-bit RGB, all five filter types
+    p.write_bytes(_glb_with_texture(_png(W, H, 2, [bytes(r.reshape(-1)) for r in rgb], filters=[0, 1, 2, 3][:H - 1] + [4])))
+    sc = pt.SceneLoader().load(str(p))
+    (tex,) = sc.textures
+    assert tex.shape == (H, W, 3) and np.array_equal(tex.astype(np.uint8), rgb)
+    assert sc.materials["baseColorTextureIdx"][0] == 0 and sc.materials["emissiveTextureIdx"][0] == 0      # one image, deduplicated
+    assert sc.triangles["v2"]["texCoords"][0].tolist() == [0, 0]                                          # v flipped: 1 - 1
+    # palette, 4 bits per index
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    idx = rng.integers(0, 16, (H, 6), dtype=np.uint8)
+    rows = [bytes((int(r[2 * k]) << 4) | int(r[2 * k + 1]) for k in range(3)) for r in idx]
+    p.write_bytes(_glb_with_texture(_png(6, H, 3, rows, bit_depth=4, palette=pal.reshape(-1))))
+    (tex,) = pt.SceneLoader().load(str(p)).textures
+    assert np.array_equal(tex.astype(np.uint8), pal[idx])
+    # 16-bit RGB: high byte is kept
+    hi = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    rows16 = [bytes(b for v in r.reshape(-1) for b in (int(v), 7)) for r in hi]
+    p.write_bytes(_glb_with_texture(_png(W, H, 2, rows16, bit_depth=16)))
+    (tex,) = pt.SceneLoader().load(str(p)).textures
+    assert np.array_equal(tex.astype(np.uint8), hi)
+    # RGBA: the reference copies width*height*3 bytes out of a 4-byte-per-pixel buffer (mis-strided)
+    rgba = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    p.write_bytes(_glb_with_texture(_png(W, H, 6, [bytes(r.reshape(-1)) for r in rgba])))
+    (tex,) = pt.SceneLoader().load(str(p)).textures
+    assert np.array_equal(tex.astype(np.uint8).reshape(-1), rgba.reshape(-1)[:W * H * 3])
+    # palette + tRNS -> 4 channels -> same mis-stride
+    p.write_bytes(_glb_with_texture(_png(6, H, 3, rows, bit_depth=4, palette=pal.reshape(-1), trns=[0, 128])))
+    (tex,) = pt.SceneLoader().load(str(p)).textures
+    alpha = np.full((16,), 255, np.uint8); alpha[0] = 0; alpha[1] = 128
+    expanded = np.concatenate([pal[idx], alpha[idx][..., None]], axis=2)
+    assert np.array_equal(tex.astype(np.uint8).reshape(-1), expanded.reshape(-1)[:6 * H * 3])
+    # grey (1 channel): the reference would read past the decoded buffer -> refused
+    grey = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    p.write_bytes(_glb_with_texture(_png(W, H, 0, [bytes(r) for r in grey])))
+    with pytest.raises(RuntimeError):
+        pt.SceneLoader().load(str(p))
+    # not a PNG at all (e.g. JPEG bytes)
+    p.write_bytes(_glb_with_texture(b"\xff\xd8\xff\xe0" + bytes(64)))
+    with pytest.raises(RuntimeError):
+        pt.SceneLoader().load(str(p))
