@@ -155,6 +155,13 @@ PT_API pt_status pt_host_bvh_build(const pt_triangle *triangles, size_t n_triang
                                    pt_bvh_info *info, float *bounds6, uint32_t *links4,
                                    int *tri_indices);
 
+/* Host-only build of the opt-in SAH tree (pt_set_bvh_mode(dev, 1)): pairs16 receives up to
+ * n_triangles NodePair records of 16 dwords {L box: xmin xmax ymin ymax zmin zmax, R box: 6 floats,
+ * llink lcnt rlink rcnt}; order[slot] = face stored at leaf-order slot `slot`.  info->nodes is the
+ * number of pairs.  Either array may be NULL.                                             */
+PT_API pt_status pt_host_sah_build(const pt_triangle *triangles, size_t n_triangles, pt_bvh_info *info,
+                                   float *pairs16, int *order);
+
 /* Framebuffer.h:27-35 replacement for cudaMallocManaged: device-local buffers + explicit
  * download (the reference relies on UVM page migration as its implicit gather).         */
 PT_API pt_status pt_fb_alloc(pt_device *dev, int width, int height, uint8_t **rgb_device,

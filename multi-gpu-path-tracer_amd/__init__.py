@@ -6,14 +6,15 @@ the tests.  Import it with importlib.import_module("multi-gpu-path-tracer_amd").
 """
 from . import _capi as capi
 from .host import (CameraConfig, DevicePathTracer, Framebuffer, HostScene, RendererConfig, RenderTask,
-                   Resolution, SceneLoader, FSFL, DSFL, DSDL, host_bvh_build, make_terrain_scene, write_ppm)
+                   Resolution, SceneLoader, FSFL, DSFL, DSDL, host_bvh_build, host_sah_build, make_terrain_scene,
+                   write_ppm)
 from .scheduling import (RenderManager, TaskGenerator, band_row_ranges, gather_frame, get_task_layout,
                          pack_bands, pack_bands_strided, packed_size, row_band_tasks, unpack_bands,
                          unpack_bands_strided)
 
 __all__ = [
     "capi", "CameraConfig", "DevicePathTracer", "Framebuffer", "HostScene", "RendererConfig", "RenderTask",
-    "Resolution", "SceneLoader", "FSFL", "DSFL", "DSDL", "host_bvh_build", "make_terrain_scene", "write_ppm",
+    "Resolution", "SceneLoader", "FSFL", "DSFL", "DSDL", "host_bvh_build", "host_sah_build", "make_terrain_scene", "write_ppm",
     "RenderManager", "TaskGenerator", "band_row_ranges", "gather_frame", "get_task_layout", "pack_bands",
     "packed_size", "row_band_tasks", "unpack_bands", "pack_bands_strided", "unpack_bands_strided",
 ]

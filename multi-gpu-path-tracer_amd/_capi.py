@@ -87,6 +87,7 @@ _PROTOS = {
     "pt_bvh_info_read": (C.c_int, [_vp, C.POINTER(BvhInfo)]),
     "pt_bvh_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "pt_host_bvh_build": (C.c_int, [_vp, C.c_size_t, C.POINTER(BvhInfo), _vp, _vp, _vp]),
+    "pt_host_sah_build": (C.c_int, [_vp, C.c_size_t, C.POINTER(BvhInfo), _vp, _vp]),
     "pt_fb_alloc": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
     "pt_fb_free": (C.c_int, [_vp, _vp, _vp]),
     "pt_fb_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),

@@ -265,11 +265,29 @@ struct SahBuilder {
             mid = (uint32_t)(it - tris.begin());
             if (mid == lo || mid == hi) mid = lo + n / 2;
         }
-        int l = build(lo, mid, depth + 1);
-        int r = build(mid, hi, depth + 1);
+        int l, r;
+        if (n >= kParallelMin && depth < 6) {
+            // big subtrees: the left half on another host thread with its own node pool (the two
+            // halves touch disjoint ranges of `tris`), merged behind this pool afterwards.  The
+            // resulting tree does not depend on the thread schedule.
+            SahBuilder other(tris);
+            auto fut = std::async(std::launch::async, [&other, lo, mid, depth] { return other.build(lo, mid, depth + 1); });
+            r = build(mid, hi, depth + 1);
+            int lroot = fut.get();
+            const int base = (int)nodes.size();
+            for (SahNode nd : other.nodes) {
+                if (nd.left >= 0) { nd.left += base; nd.right += base; }
+                nodes.push_back(nd);
+            }
+            l = lroot + base;
+        } else {
+            l = build(lo, mid, depth + 1);
+            r = build(mid, hi, depth + 1);
+        }
         nodes[id].left = l; nodes[id].right = r;
         return id;
     }
+    static constexpr uint32_t kParallelMin = 1u << 17;
 };
 
 } // namespace

@@ -1,6 +1,7 @@
 // pt_common.cpp -- error reporting and the host-side task generators of the C ABI.
 #include "pt_internal.h"
 
+#include <cstring>
 #include <vector>
 
 namespace pt {
@@ -48,6 +49,30 @@ pt_status pt_host_bvh_build(const pt_triangle *tris, size_t n, pt_bvh_info *info
         if (links4) { uint32_t *l = links4 + 4 * i; l[0] = nd.left; l[1] = nd.right; l[2] = nd.firstTri; l[3] = nd.triCount; }
     }
     if (tri_indices) for (size_t i = 0; i < n; i++) tri_indices[i] = bvh.indices[i];
+    return PT_OK;
+}
+
+pt_status pt_host_sah_build(const pt_triangle *tris, size_t n, pt_bvh_info *info, float *pairs16, int *order)
+{
+    clear_error();
+    if (!tris || n == 0) return set_error(PT_ERR_INVALID, "no triangles");
+    std::vector<float> pos(9 * n);
+    for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            pos[9 * i + k] = tris[i].v0.position[k];
+            pos[9 * i + 3 + k] = tris[i].v1.position[k];
+            pos[9 * i + 6 + k] = tris[i].v2.position[k];
+        }
+    SahBvh bvh;
+    build_sah_bvh(pos.data(), n, bvh);
+    if (info) {
+        info->nodes = (uint32_t)bvh.pairs.size(); info->leaves = 0; info->max_leaf = bvh.max_leaf; info->depth = bvh.max_stack;
+        info->max_stack = bvh.max_stack; info->lights = 0; info->triangles = (uint32_t)n;
+        for (const NodePair &p : bvh.pairs) info->leaves += (p.lcnt != 0) + (p.rcnt != 0);
+    }
+    static_assert(sizeof(NodePair) == 64, "NodePair is 16 dwords");
+    if (pairs16) memcpy(pairs16, bvh.pairs.data(), bvh.pairs.size() * sizeof(NodePair));
+    if (order) memcpy(order, bvh.order.data(), n * sizeof(int));
     return PT_OK;
 }
 

@@ -377,3 +377,14 @@ def host_bvh_build(triangles: np.ndarray):
                                             capi.np_ptr(links), capi.np_ptr(idx)))
     k = info.nodes
     return info.as_dict(), bounds[:k], links[:k], idx
+
+
+def host_sah_build(triangles: np.ndarray):
+    """Host-only build of the opt-in SAH tree: (info, pairs [n_pairs, 16] float32 view, order)."""
+    tris = np.ascontiguousarray(triangles, dtype=capi.TRIANGLE_DTYPE)
+    n = len(tris)
+    info = capi.BvhInfo()
+    pairs = np.zeros((max(n, 1), 16), np.float32)
+    order = np.zeros(n, np.int32)
+    capi.check(capi.lib().pt_host_sah_build(capi.np_ptr(tris), n, C.byref(info), capi.np_ptr(pairs), capi.np_ptr(order)))
+    return info.as_dict(), pairs[:info.nodes], order

@@ -408,3 +408,34 @@ def test_embedded_png_variants(pt, tmp_path):
     p.write_bytes(_glb_with_texture(b"\xff\xd8\xff\xe0" + bytes(64)))
     with pytest.raises(RuntimeError):
         pt.SceneLoader().load(str(p))
+
+
+def test_sah_tree_invariants_and_determinism(pt, duck_scene):
+    """Opt-in SAH tree (host build, threaded for big inputs): every triangle sits in exactly one leaf
+    of <= 4, every child box (inflated) contains its triangles, child links form a tree in which
+    pair 0 is the root, and the result does not depend on the thread schedule."""
+    for tris in (duck_scene.triangles, pt.make_terrain_scene(300).triangles):      # 4224 and 180002 triangles
+        info, pairs, order = pt.host_sah_build(tris)
+        info2, pairs2, order2 = pt.host_sah_build(tris)
+        assert np.array_equal(pairs.view(np.uint32), pairs2.view(np.uint32)) and np.array_equal(order, order2)
+        n = len(tris)
+        assert sorted(order.tolist()) == list(range(n)) and info["max_leaf"] <= 4 and info["max_stack"] <= 64
+        links = pairs[:, 12:16].view(np.uint32)
+        boxes = pairs[:, :12]
+        pos = np.stack([tris[v]["position"] for v in ("v0", "v1", "v2")], axis=1)[order]      # leaf order
+        seen_pairs = np.zeros(len(pairs), np.int32); seen_pairs[0] = 1
+        covered = np.zeros(n, np.int32)
+        for p in range(len(pairs)):
+            for side in (0, 1):
+                link, cnt = int(links[p, 2 * side]), int(links[p, 2 * side + 1])
+                b = boxes[p, 6 * side: 6 * side + 6]
+                if cnt == 0:
+                    assert link > p                      # pre-order: children come later
+                    seen_pairs[link] += 1
+                elif np.isfinite(b).all():
+                    covered[link:link + cnt] += 1
+                    pts = pos[link:link + cnt].reshape(-1, 3)
+                    assert (pts[:, 0] >= b[0]).all() and (pts[:, 0] <= b[1]).all()
+                    assert (pts[:, 1] >= b[2]).all() and (pts[:, 1] <= b[3]).all()
+                    assert (pts[:, 2] >= b[4]).all() and (pts[:, 2] <= b[5]).all()
+        assert (covered == 1).all() and (seen_pairs == 1).all()
