@@ -439,3 +439,12 @@ def test_sah_tree_invariants_and_determinism(pt, duck_scene):
                     assert (pts[:, 1] >= b[2]).all() and (pts[:, 1] <= b[3]).all()
                     assert (pts[:, 2] >= b[4]).all() and (pts[:, 2] <= b[5]).all()
         assert (covered == 1).all() and (seen_pairs == 1).all()
+
+
+def test_missing_native_library_fails_loudly(pt, monkeypatch):
+    """No silent fallback: without libptamd.so the binding raises at first use."""
+    monkeypatch.setattr(pt.capi, "_lib", None)
+    monkeypatch.setattr(pt.capi, "LIB_PATH", "/nonexistent/libptamd.so")
+    with pytest.raises(ImportError) as e:
+        pt.capi.lib()
+    assert "no fallback" in str(e.value)
