@@ -133,7 +133,15 @@ __global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P)
         const int total = __popcll(__ballot(walking));
         if (total == 0) break;                            // wave-uniform: nobody has work left
         while (true) {
-            if (walking) walking = sah_step(P, W, L.ro, L.rd, 0.001f, stack, kBlock, L.n_box, L.n_tri);
+            // one kind of micro-step per trip, chosen by majority vote: the minority waits a trip
+            // rather than making the whole wave run its block for a few lanes
+            const int want_tri = __popcll(__ballot(walking && W.n0 != 0));
+            const int want_node = __popcll(__ballot(walking && W.n0 == 0));
+            if (want_tri >= want_node) {
+                if (walking && W.n0 != 0) walking = sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
+            } else {
+                if (walking && W.n0 == 0) walking = sah_node_step(P, W, L.ro, L.rd, stack, kBlock, L.n_box);
+            }
             const int still = __popcll(__ballot(walking));
             if (still * 100 <= total * P.spec_pct) break;
         }
@@ -253,7 +261,7 @@ struct pt_device {
     int walk = 0;                 // traversal schedule: 0 per-lane, 1 uniform/mask, 2 uniform/stack, 3 SAH tree
     bool sah = false;             // uploaded with the opt-in SAH tree instead of the reference topology
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
-    int spec_pct = 65;            // ... and leaves the walk loop when <= this % of the walkers remain
+    int spec_pct = 50;            // ... and leaves the walk loop when <= this % of the walkers remain
     int bvh_mode = 0;             // pt_set_bvh_mode: applies to the next pt_upload_scene
     int force_walk = -1;          // pt_set_traversal_mode: -1 auto, else the requested schedule
     int queue_entries = 8;        // per-lane leaf queue capacity (phase A -> phase B)

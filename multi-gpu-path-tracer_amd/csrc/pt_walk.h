@@ -331,12 +331,10 @@ __device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
 // loop that only the lanes standing on a leaf take part in (PMC before: 19 % VALU lane
 // utilisation on the duck).  Pending triangles go first, so the next node visit prunes against
 // the closest hit they may have produced.  Returns false when the walk is complete.
-__device__ __forceinline__ bool sah_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin,
-                                         uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
+__device__ __forceinline__ bool sah_tri_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin, uint32_t &n_tri)
 {
-    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
     const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
-    if (W.n0 != 0) {
+    {
         const float4 *tp = tris + 3 * (size_t)W.k0;
         const float4 ta = tp[0], tb = tp[1], tc = tp[2];
         float t, u, v;
@@ -350,7 +348,12 @@ __device__ __forceinline__ bool sah_step(const RenderParams &P, SahWalk &W, v3 o
         if (W.n0 == 0) { W.k0 = W.k1; W.n0 = W.n1; W.n1 = 0; }
         return W.n0 != 0 || W.more_nodes;
     }
-    // node visit
+}
+
+__device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, uint32_t *stack, int stride,
+                                              uint32_t &n_box)
+{
+    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
     const float4 *np = nodes + 4 * (size_t)W.pair;
     const float4 a = np[0], b = np[1], c = np[2], lf = np[3];
     const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
@@ -393,6 +396,13 @@ __device__ __forceinline__ bool sah_step(const RenderParams &P, SahWalk &W, v3 o
         W.pair = stack[W.sp * stride];
     }
     return W.n0 != 0 || W.more_nodes;
+}
+
+__device__ __forceinline__ bool sah_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin,
+                                         uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
+{
+    if (W.n0 != 0) return sah_tri_step(P, W, o, d, tmin, n_tri);
+    return sah_node_step(P, W, o, d, stack, stride, n_box);
 }
 
 __device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
