@@ -769,7 +769,8 @@ pt_status pt_scene_make_terrain(unsigned grid, pt_host_scene **out)
     grey.baseColorTextureIdx = grey.emissiveTextureIdx = -1;
     pt_material light = grey;
     light.baseColor[0] = light.baseColor[1] = light.baseColor[2] = 0.0f;
-    light.emissiveFactor[0] = light.emissiveFactor[1] = light.emissiveFactor[2] = 1.0f;
+    // emitted radiance = emissiveFactor * 50 (material.h:85): 0.25 keeps most of the lit terrain inside 0..255
+    light.emissiveFactor[0] = light.emissiveFactor[1] = light.emissiveFactor[2] = 0.25f;
     sc.materials = {grey, light};
     sc.material_names = {"lambertian_terrain", "diffuse_light"};
     auto hash = [](uint32_t x, uint32_t z) {
