@@ -44,20 +44,23 @@ def algorithmic_bytes(cnt, pixels):
             + 4.5 * pixels)
 
 
-def measured_traffic(config):
+def measured_traffic(config, workload=None):
     """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes
     (profiles/*_<config>_pmc_summary.json, FETCH_SIZE / WRITE_SIZE collected in separate passes and
-    corrected as MI355X_MICROARCH.md prescribes); None when no profile of this config is committed."""
+    corrected as MI355X_MICROARCH.md prescribes); None when no profile of this config AND the same
+    workload string (frame size, spp, depth, tree) is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pmc_summary.json" % config)))
-    if not files:
-        return None, None, None
-    try:
-        with open(files[-1]) as f:
-            d = json.load(f)
-        return float(d["hbm_bytes_per_launch"]["total"]), os.path.relpath(files[-1], ROOT), d.get("valu_roofline")
-    except Exception:
-        return None, None, None
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if workload is not None and d["bench_line_under_kernel_trace"]["config"]["workload"] != workload:
+                continue
+            return float(d["hbm_bytes_per_launch"]["total"]), os.path.relpath(path, ROOT), d.get("valu_roofline")
+        except Exception:
+            continue
+    return None, None, None
 
 
 def load_scene(pt, kind):
@@ -86,6 +89,17 @@ def cpu_baseline(scene, camera, W, H, spp, depth, budget_rows):
         "sample": "task %dx%d at offset_y=%d of the %dx%d frame (%.1f%% of pixels), %d spp, %d bounces, %.1f s"
                   % (W, rows, oy, W, H, 100.0 * rows / H, spp, depth, dt),
     }
+
+
+ROOFLINE_NOTES = {
+    "c2": "algorithmic bytes (SURVEY 8d) are served by the scalar cache / L1 on this KB-sized scene; "
+          "the HBM traffic of a launch is `traffic` bytes, the kernel is VALU-issue bound (DESIGN.md 4)",
+    "c3": "algorithmic bytes (SURVEY 8d) are served by L1/L2 (0.7 MB of tree + 3 MB texture); the HBM traffic of "
+          "a launch is `traffic` bytes; the SAH kernel is issue/divergence bound (DESIGN.md 4)",
+    "c4": "1 GB scene: `traffic` (PMC) is what reaches HBM after L2 + Infinity Cache; the SAH kernel is "
+          "memory-latency bound here (one dependent node or triangle fetch per micro-step, DESIGN.md 4)",
+}
+ROOFLINE_NOTES["c1"] = ROOFLINE_NOTES["c5"] = ROOFLINE_NOTES["c2"]
 
 
 def main():
@@ -206,7 +220,7 @@ def main():
         achieved = bytes_rank0 / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic, traffic_src, valu = (None, None, None)
         if world == 1 and not (args.width or args.height) and bvh == "reference":
-            traffic, traffic_src, valu = measured_traffic(args.config)
+            traffic, traffic_src, valu = measured_traffic(args.config, desc)
         out = {
             "metric": "ray-segments/s", "value": seg_per_s, "unit": "ray-segments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -223,8 +237,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_rank0 / max(launches, 1),
                 "valu_roofline_from_profile": valu,
-                "note": "algorithmic bytes (SURVEY 8d) are served by the scalar cache / L1 on this KB-sized scene; "
-                        "the HBM traffic of a launch is `traffic` bytes, the kernel is VALU-issue bound (DESIGN.md 4)",
+                "note": ROOFLINE_NOTES.get(args.config, ROOFLINE_NOTES["c2"]),
                 "kernel": "pt::dev::render_kernel", "kernel_ms_avg": kernel_ms / max(launches, 1),
                 "launches": launches,
                 "algorithmic_bytes_per_segment": bytes_rank0 / max(cnt["segments"], 1),
