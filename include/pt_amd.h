@@ -181,6 +181,15 @@ PT_API pt_status pt_fb_download_task(pt_device *dev, const pt_task *task, uint8_
  * 4: XORWOW uniform #b (0-based) of seed (uint32)a bits -> out0.                          */
 PT_API pt_status pt_kat_arith(pt_device *dev, int op, const float *a, const float *b,
                               float *out0, float *out1, size_t n);
+/* Exhaustive proof obligations of the kernels' short division forms (pt_math.h): runs the bit
+ * patterns first_bits .. first_bits+count-1 (count <= 2^32) through the short form and through the
+ * IEEE expression it replaces (op 0: 1.0f/x; op 1: (float)((double)x / pi); op 2: 1.0f/x for
+ * |x| > 1e-8 only, the Moller-Trumbore form; op 3: the unguarded core, which must fail) on the
+ * GPU; *n_bad =
+ * number of inputs whose results differ in any bit (NaN == NaN), the first max_examples of them
+ * (unordered) are written to examples.                                                        */
+PT_API pt_status pt_kat_exhaustive(pt_device *dev, int op, uint32_t first_bits, uint64_t count,
+                                   uint64_t *n_bad, uint32_t *examples, int max_examples);
 /* Closest hit of n rays through the device traversal: o/d are 3 floats per ray; outputs
  * t (or -1 on miss) and the face index in the uploaded triangle order (-1 on miss).     */
 PT_API pt_status pt_kat_closest_hit(pt_device *dev, const float *origins, const float *dirs,

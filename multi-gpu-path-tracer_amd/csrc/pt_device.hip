@@ -176,6 +176,30 @@ __global__ void kat_arith_kernel(int op, const float *a, const float *b, float *
     if (o1) o1[i] = r1;
 }
 
+// All bit patterns first .. first+count-1 through a short form and the IEEE expression it replaces.
+__global__ void kat_exhaustive_kernel(int op, uint32_t first, uint64_t count, unsigned long long *n_bad,
+                                      uint32_t *examples, int max_examples)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint32_t bits = first + (uint32_t)i;
+        const float x = __uint_as_float(bits);
+        float want, got;
+        if (op == 0) { want = 1.0f / x; got = pt_rcp(x); }
+        else if (op == 1) { want = (float)((double)x / M_PI); got = pt_div_pi(x); }
+        else if (op == 2) { want = 1.0f / x; got = pt_rcp_not_tiny(x); if (__builtin_fabsf(x) <= 1e-8f) got = want; }
+        else { want = 1.0f / x; got = pt_rcp_core(x); }      // unguarded: shows the checker can fail
+        const bool same = (__float_as_uint(want) == __float_as_uint(got)) || (want != want && got != got);
+        if (!same) {
+            bad++;
+            unsigned long long k = atomicAdd(&n_bad[1], 1ull);
+            if (k < (unsigned long long)max_examples) examples[k] = bits;
+        }
+    }
+    if (bad) atomicAdd(&n_bad[0], bad);
+}
+
 __global__ void kat_hit_kernel(RenderParams P, const float *org, const float *dir, float *t_out,
                                int *face_out, size_t n)
 {
@@ -948,6 +972,34 @@ pt_status pt_kat_arith(pt_device *dev, int op, const float *a, const float *b, f
     PT_HIP(hipMemcpy(out0, d0, bytes, hipMemcpyDeviceToHost));
     if (out1) PT_HIP(hipMemcpy(out1, d1, bytes, hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(d0); (void)hipFree(d1);
+    return PT_OK;
+}
+
+pt_status pt_kat_exhaustive(pt_device *dev, int op, uint32_t first_bits, uint64_t count, uint64_t *n_bad,
+                            uint32_t *examples, int max_examples)
+{
+    clear_error();
+    if (!dev || !n_bad || op < 0 || op > 3 || max_examples < 0 || (max_examples > 0 && !examples) ||
+        count > (1ull << 32))
+        return set_error(PT_ERR_INVALID, "bad argument");
+    *n_bad = 0;
+    if (count == 0) return PT_OK;
+    PT_HIP(hipSetDevice(dev->index));
+    unsigned long long *dbad = nullptr; uint32_t *dex = nullptr;
+    PT_HIP(hipMalloc((void **)&dbad, 16));
+    PT_HIP(hipMalloc((void **)&dex, sizeof(uint32_t) * (size_t)(max_examples > 0 ? max_examples : 1)));
+    PT_HIP(hipMemset(dbad, 0, 16));
+    PT_HIP(hipMemset(dex, 0, sizeof(uint32_t) * (size_t)(max_examples > 0 ? max_examples : 1)));
+    uint64_t want_blocks = (count + 255) / 256;
+    unsigned blocks = (unsigned)(want_blocks < 65536 ? want_blocks : 65536);
+    hipLaunchKernelGGL(dev::kat_exhaustive_kernel, dim3(blocks), dim3(256), 0, 0, op, first_bits, count, dbad, dex, max_examples);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipDeviceSynchronize());
+    unsigned long long host_bad[2] = {0, 0};
+    PT_HIP(hipMemcpy(host_bad, dbad, 16, hipMemcpyDeviceToHost));
+    if (max_examples > 0) PT_HIP(hipMemcpy(examples, dex, sizeof(uint32_t) * (size_t)max_examples, hipMemcpyDeviceToHost));
+    (void)hipFree(dbad); (void)hipFree(dex);
+    *n_bad = host_bad[0];
     return PT_OK;
 }
 

@@ -239,10 +239,10 @@ __device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const
     }
     v3 ndir = normalize(dir);
     float cosv = dot(ndir, uvw.a2);                                // cosine_pdf::value, pdf.h:19-22
-    float cpdf = (cosv <= 0) ? 0.0f : (float)((double)cosv / M_PI);
+    float cpdf = (cosv <= 0) ? 0.0f : pt_div_pi(cosv);
     float pdf_value = 0.5f * lsum + 0.5f * cpdf;                   // mixture_pdf::value, pdf.h:63-65
     float cos2 = dot(normal, ndir);                                // scattering_pdf, material.h:88-91
-    float spdf = cos2 < 0 ? 0.0f : (float)((double)cos2 / M_PI);
+    float spdf = cos2 < 0 ? 0.0f : pt_div_pi(cos2);
     L.atten = L.atten * ((albedo * spdf) / pdf_value);                 // camera.h:69
     L.ro = p; L.rd = dir;
     L.bounce++;

@@ -41,7 +41,7 @@ __device__ __forceinline__ bool tri_hit(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float t
     // triangle.h:78 compares in double against +-1e-8; for a float det that is exactly
     // |det| <= 1e-8f (1e-8f < 1e-8 < nextafter(1e-8f)).
     bool ok = !(det <= 1e-8f && det >= -1e-8f);
-    float inv_det = 1.0f / det;                       // :84 (double divide == IEEE 1.0f/det)
+    float inv_det = pt_rcp_not_tiny(det);             // :84 (double divide == IEEE 1.0f/det; pt_math.h)
     v3 tvec = o - v0;
     float u = dot(tvec, pvec) * inv_det;
     ok = ok && !(u < 0 || u > 1);
@@ -61,7 +61,7 @@ __device__ __forceinline__ bool mt_eval(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float &
     v3 pvec = cross(d, e2);
     float det = dot(e1, pvec);
     bool ok = !((det <= 1e-8f) & (det >= -1e-8f));
-    float inv_det = 1.0f / det;
+    float inv_det = pt_rcp_not_tiny(det);
     v3 tvec = o - v0;
     u = dot(tvec, pvec) * inv_det;
     ok = ok & !((u < 0) | (u > 1));
@@ -120,7 +120,7 @@ __device__ __forceinline__ Hit traverse(const SceneView<kLds> S, v3 o, v3 d, flo
 {
     Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
     float tmax = tmax0;
-    v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    v3 inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
     uint32_t pair = 0;
     int sp = 0;
     bool walking = true;
@@ -190,7 +190,7 @@ __device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 
 {
     Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
     float tmax = tmax0;
-    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const v3 inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
     const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
     const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
     unsigned long long act = 1ull;                       // bit p: pair p is on this lane's path
@@ -241,7 +241,7 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
 {
     Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
     float tmax = tmax0;
-    const v3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const v3 inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
     const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
     const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
     uint32_t next = 0;
@@ -318,7 +318,7 @@ struct SahWalk {
 __device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
 {
     W.pair = 0; W.sp = 0; W.tbest = tmax0; W.best_rank = 0xFFFFFFFFu;
-    W.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    W.inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
     W.h.t = 0.0f; W.h.u = 0.0f; W.h.v = 0.0f; W.h.slot = -1;
     W.k0 = W.n0 = W.k1 = W.n1 = 0;
     W.more_nodes = true;

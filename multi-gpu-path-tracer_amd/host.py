@@ -347,6 +347,14 @@ class DevicePathTracer:
                                            capi.np_ptr(o1), a.size))
         return o0, o1
 
+    def katExhaustive(self, op: int, first_bits: int = 0, count: int = 1 << 32, max_examples: int = 16):
+        """(number of differing inputs, example bit patterns) of pt_kat_exhaustive."""
+        bad = C.c_uint64(0)
+        ex = np.zeros(max(max_examples, 1), np.uint32)
+        capi.check(capi.lib().pt_kat_exhaustive(self._h, op, first_bits, count, C.byref(bad), capi.np_ptr(ex),
+                                                max_examples))
+        return int(bad.value), ex[:min(int(bad.value), max_examples)]
+
     def katClosestHit(self, origins: np.ndarray, dirs: np.ndarray):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
