@@ -184,7 +184,7 @@ PT_API pt_status pt_kat_arith(pt_device *dev, int op, const float *a, const floa
 /* Exhaustive proof obligations of the kernels' short division forms (pt_math.h): runs the bit
  * patterns first_bits .. first_bits+count-1 (count <= 2^32) through the short form and through the
  * IEEE expression it replaces (op 0: 1.0f/x; op 1: (float)((double)x / pi); op 2: 1.0f/x for
- * |x| > 1e-8 only, the Moller-Trumbore form; op 3: the unguarded core, which must fail) on the
+ * |x| > 1e-8 only, the Moller-Trumbore form; op 3: the unguarded core, which must fail; op 4: sqrtf(x)) on the
  * GPU; *n_bad =
  * number of inputs whose results differ in any bit (NaN == NaN), the first max_examples of them
  * (unordered) are written to examples.                                                        */

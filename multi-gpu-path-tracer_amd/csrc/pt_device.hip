@@ -189,7 +189,8 @@ __global__ void kat_exhaustive_kernel(int op, uint32_t first, uint64_t count, un
         if (op == 0) { want = 1.0f / x; got = pt_rcp(x); }
         else if (op == 1) { want = (float)((double)x / M_PI); got = pt_div_pi(x); }
         else if (op == 2) { want = 1.0f / x; got = pt_rcp_not_tiny(x); if (__builtin_fabsf(x) <= 1e-8f) got = want; }
-        else { want = 1.0f / x; got = pt_rcp_core(x); }      // unguarded: shows the checker can fail
+        else if (op == 3) { want = 1.0f / x; got = pt_rcp_core(x); }  // unguarded: shows the checker can fail
+        else { want = sqrtf(x); got = pt_sqrt(x); }
         const bool same = (__float_as_uint(want) == __float_as_uint(got)) || (want != want && got != got);
         if (!same) {
             bad++;
@@ -979,7 +980,7 @@ pt_status pt_kat_exhaustive(pt_device *dev, int op, uint32_t first_bits, uint64_
                             uint32_t *examples, int max_examples)
 {
     clear_error();
-    if (!dev || !n_bad || op < 0 || op > 3 || max_examples < 0 || (max_examples > 0 && !examples) ||
+    if (!dev || !n_bad || op < 0 || op > 4 || max_examples < 0 || (max_examples > 0 && !examples) ||
         count > (1ull << 32))
         return set_error(PT_ERR_INVALID, "bad argument");
     *n_bad = 0;

@@ -53,6 +53,20 @@ __device__ __forceinline__ float pt_rcp_not_tiny(float x)
     if (__builtin_expect(__any(__builtin_fabsf(x) > 0x1p126f), 0)) r = 1.0f / x;
     return r;
 }
+// v_rsq (1 ulp) -> s = x*y, h = y/2, one residual step s + (x - s*s)*h in FMA.  Measured exhaustively:
+// equals sqrtf(x) for every finite x >= 2^-102; below that (residual underflows), for zero, negatives,
+// infinity and NaN the wave takes the compiler's sequence.
+__device__ __forceinline__ float pt_sqrt(float x)                               // == sqrtf(x)
+{
+    float y = __builtin_amdgcn_rsqf(x);
+    float s = x * y;
+    float h = 0.5f * y;
+    float r = __builtin_fmaf(-s, s, x);
+    s = __builtin_fmaf(r, h, s);
+    const bool odd = !((x >= 0x1p-100f) & (x <= 3.402823466e+38f));
+    if (__builtin_expect(__any(odd), 0)) s = sqrtf(x);
+    return s;
+}
 // x * (1/pi) in double, one FMA residual correction, round to float: equals the double division's
 // float for all 2^32 inputs except -0 and +-inf, which the class test passes through.
 __device__ __forceinline__ float pt_div_pi(float x)                             // == (float)((double)x / M_PI)
@@ -80,11 +94,18 @@ PT_HD v3 cross(v3 a, v3 b)
 {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-PT_HD float length(v3 v) { return sqrtf(dot(v, v)); }                           // :1309
+PT_HD float length(v3 v)                                                        // :1309
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return pt_sqrt(dot(v, v));
+#else
+    return sqrtf(dot(v, v));
+#endif
+}
 PT_HD v3 normalize(v3 v)                                                        // :1327 + :80
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    float inv = pt_rcp(sqrtf(dot(v, v)));
+    float inv = pt_rcp(pt_sqrt(dot(v, v)));
 #else
     float inv = 1.0f / sqrtf(dot(v, v));
 #endif

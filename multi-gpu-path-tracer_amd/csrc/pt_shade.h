@@ -206,17 +206,17 @@ __device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const
         const float4 *lp = V.lights + 5 * (size_t)idx;
         float4 la = lp[0], ld = lp[3], le = lp[4];
         float r1 = xorwow_uniform(L.rng), r2 = xorwow_uniform(L.rng);  // triangle::random, triangle.h:41-47
-        float sq = sqrtf(r1);
+        float sq = pt_sqrt(r1);
         v3 lv0 = mk3(la.x, la.y, la.z), lv1 = mk3(ld.x, ld.y, ld.z), lv2 = mk3(ld.w, le.x, le.y);
         v3 rp = ((1 - sq) * lv0 + (sq * (1 - r2)) * lv1) + (sq * r2) * lv2;
         dir = rp - p;
     } else {
         float r1 = xorwow_uniform(L.rng), r2 = xorwow_uniform(L.rng);  // random_cosine_direction, helper_math.h:1519-1527
-        float z = sqrtf(1 - r2);
+        float z = pt_sqrt(1 - r2);
         float phi = (float)(2 * M_PI * (double)r1);
         float sn, cs;
         pt_sincosf(phi, sn, cs);
-        float sq2 = sqrtf(r2);
+        float sq2 = pt_sqrt(r2);
         float lx = cs * 2 * sq2, ly = sn * 2 * sq2;
         dir = (lx * uvw.a0 + ly * uvw.a1) + z * uvw.a2;            // onb::local, onb.h:20-22
     }

@@ -72,12 +72,13 @@ def test_device_arithmetic_is_ieee_and_matches_oracle(pt, ob, box_scene, gpu_dev
 
 def test_short_division_forms_equal_ieee_for_every_float(pt, box_scene, gpu_device):
     """The kernels' short reciprocal (v_rcp + Newton step + v_div_fixup, IEEE sequence outside
-    2^-126..2^126) and x/pi (double multiply + FMA residual) forms against the IEEE expressions they
+    2^-126..2^126), x/pi (double multiply + FMA residual) and sqrt (v_rsq + residual step, IEEE sequence
+    below 2^-100) forms against the IEEE expressions they
     replace, over ALL 2^32 float bit patterns: not one differing bit (pt_math.h, pt_kat_exhaustive).
     The IEEE expressions themselves are pinned to the host's by the sampled test above."""
     fb = pt.Framebuffer(pt.Resolution(8, 8))
     tr = pt.DevicePathTracer(0, 1, 1, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
-    for op in (0, 1, 2):
+    for op in (0, 1, 2, 4):
         bad, examples = tr.katExhaustive(op, 0, 1 << 32, 8)
         assert bad == 0, (op, bad, ["%08x" % b for b in examples])
     # the checker itself must be able to fail: the unguarded core is wrong for |x| > 2^126 (op 3)
