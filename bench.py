@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile-schedule", type=int, default=1, choices=[0, 1],
+                    help="0: tiles in raster order; 1: ordered by their cost in the previous frame (pt_set_tile_schedule)")
     ap.add_argument("--cpu-rows", type=int, default=360)
     ap.add_argument("--ppm", default=None, help="write the gathered frame of the last step here")
     ap.add_argument("--bvh", default=None, choices=["reference", "sah"],
@@ -160,6 +162,7 @@ def main():
     mgr = pt.RenderManager(cfg, scene, cam, device_idx=local_rank, band_rows=args.band_rows,
                            bvh_mode=1 if bvh == "sah" else 0)
     upload_s = time.perf_counter() - t_up
+    mgr.tracer.setTileSchedule(args.tile_schedule)
 
     if args.share_of > 1 and world == 1:
         # what one rank of an N-GPU run computes, measured on this GPU alone (no gather)
@@ -227,6 +230,7 @@ def main():
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "scene": kind, "width": W, "height": H, "spp": spp, "bounces": depth,
+                       "tile_schedule": "cost order from the previous frame" if args.tile_schedule else "raster order",
                        "parallelism": "row-bands x%d (band_rows=%d), scene replicated, gather to rank 0"
                                       % (world, args.band_rows)},
             "segments_per_frame": total["segments"] // args.steps,

@@ -105,6 +105,16 @@ PT_API pt_status pt_set_thread_block_size(pt_device *dev, unsigned x, unsigned y
  * distance pruning: same Moller-Trumbore arithmetic and tie-breaking, but a
  * different set of tested triangles, so ill-conditioned rays can resolve differently.     */
 PT_API pt_status pt_set_bvh_mode(pt_device *dev, int mode);
+/* Order in which a launch hands its 8x8-pixel tiles to waves.  0: raster order.  1 (default):
+ * cost order -- every launch records what each tile cost (shader-clock ticks) and a device radix
+ * sort makes that the next launch's order for the same task rectangle / band set, dearest tiles
+ * first, so a launch no longer ends on a straggler that started last.  This is the reference's
+ * frame-to-frame feedback (DSFL/DSDL adapt task rectangles from last frame's task times,
+ * RenderManager.h:264-408) applied inside one GPU at tile granularity.  Pixels never depend on the
+ * order (per-pixel seeds), so images are byte-identical in both modes.  Up to 16 task geometries
+ * are tracked per device; launches of fewer than 4096 tiles always use raster order.          */
+PT_API pt_status pt_set_tile_schedule(pt_device *dev, int mode);
+
 /* Traversal schedule of the render kernel (same results and test counts, different order of
  * work across the lanes of a wave): 0 = auto, 1 = per-lane two-phase walk (any
  * scene), 2 = wave-uniform walk with a 64-bit path mask (trees of <= 64 inner nodes),

@@ -101,6 +101,9 @@ public:
     // opt-in SAH tree instead of the reference's topology (include/pt_amd.h: pt_set_bvh_mode)
     void setBvhMode(int mode) { checkPtErrors(pt_set_bvh_mode(dev_, mode)); reloadWorld(); }
 
+    // tiles in raster order (0) or ordered by their cost in the previous launch of the same task (1, default)
+    void setTileSchedule(int mode) { checkPtErrors(pt_set_tile_schedule(dev_, mode)); }
+
     pt_stream createStream() { pt_stream s = nullptr; checkPtErrors(pt_stream_create(dev_, &s)); return s; }
     void destroyStream(pt_stream s) { checkPtErrors(pt_stream_destroy(dev_, s)); }
     pt_counters readCounters() { pt_counters c{}; checkPtErrors(pt_counters_read(dev_, &c)); return c; }

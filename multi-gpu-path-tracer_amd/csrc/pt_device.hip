@@ -11,6 +11,7 @@
 // longest path of the wave.  The per-lane traversal stack lives in LDS.  No MFMA: this is
 // a divergent gather workload.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdlib>
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
     }
 #endif
     flush_counters(P, L, lane);
+    record_tile_cost(P, tid, wave_max(L.n_seg));      // trips of this wave's loop = segments of its busiest lane
 }
 
 // Render kernel for the SAH tree: same integrator, but the wave does not finish one ray segment
@@ -120,7 +122,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P)
     sah_begin(W, mk3(1.0f, 1.0f, 1.0f), 0.0f);
     bool alive = in_frame && P.depth > 0;
     bool walking = false;
+    uint32_t cost = 0;                                    // wave-uniform: micro-step trips + 8 per outer trip
     while (true) {
+        cost += 8;
         if (alive && !walking) {
             if (L.need_new && !start_path(L, P, x, y)) {
                 alive = false;
@@ -143,12 +147,14 @@ __global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P)
                 if (walking && W.n0 == 0) walking = sah_node_step(P, W, L.ro, L.rd, stack, kBlock, L.n_box);
             }
             const int still = __popcll(__ballot(walking));
+            cost++;
             if (still * 100 <= total * P.spec_pct) break;
         }
         if (alive && !walking) shade(L, P, V, W.h);
     }
     if (in_frame) write_pixel(P, L.col, pixel_index);
     flush_counters(P, L, lane);
+    record_tile_cost(P, tid, cost);
 }
 
 // ---- known-answer kernels (bit-exactness contract) -----------------------------------
@@ -174,6 +180,12 @@ __global__ void kat_arith_kernel(int op, const float *a, const float *b, float *
     }
     o0[i] = r0;
     if (o1) o1[i] = r1;
+}
+
+__global__ void iota_kernel(uint32_t *a, uint32_t *b, unsigned n)
+{
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = i; if (b) b[i] = i; }
 }
 
 // All bit patterns first .. first+count-1 through a short form and the IEEE expression it replaces.
@@ -264,6 +276,22 @@ using namespace pt;
                                              ":" + std::to_string(__LINE__) + " '" #call "'");   \
     } while (0)
 
+// Adaptive tile schedule of one task geometry (pt_set_tile_schedule): the render kernel records what
+// every 8x8 tile cost, a device radix sort turns that into next launch's wave-slot -> tile order
+// (dearest first), so the launch ends on cheap tiles instead of on a straggler that started last.
+struct TileSchedule {
+    int key[9];
+    unsigned slots = 0;
+    uint32_t *order = nullptr, *cost = nullptr, *sorted_cost = nullptr, *iota = nullptr;
+    void *temp = nullptr;
+    size_t temp_bytes = 0;
+    bool has_order = false;
+    hipEvent_t last_use = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+    uint64_t stamp = 0;
+};
+
 struct pt_device {
     int index = 0;
     // scene (device)
@@ -294,6 +322,10 @@ struct pt_device {
     int W = 0, H = 0;
     uint8_t *rgb = nullptr, *yuv = nullptr;
     unsigned block_x = 8, block_y = 8;
+    // adaptive tile schedule
+    int tile_schedule = 1;        // 0 raster order, 1 cost-ordered from the previous launch of the same task
+    std::vector<TileSchedule *> schedules;
+    uint64_t schedule_clock = 0;
     // kernel timing
     std::mutex mu;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_events;
@@ -312,6 +344,21 @@ static int choose_walk(const pt_device *d)
     if (d->force_walk == 1) return mask_ok ? 1 : -1;
     if (d->force_walk == 2) return stack_ok ? 2 : -1;
     return mask_ok ? 1 : (stack_ok ? 2 : 0);
+}
+
+static void free_schedule(TileSchedule *t)
+{
+    (void)hipFree(t->order); (void)hipFree(t->cost); (void)hipFree(t->sorted_cost); (void)hipFree(t->iota);
+    (void)hipFree(t->temp);
+    if (t->last_use) (void)hipEventDestroy(t->last_use);
+    delete t;
+}
+
+// Caller holds dev->mu and has synchronised the device (or knows nothing is in flight).
+static void drop_schedules(pt_device *d)
+{
+    for (TileSchedule *t : d->schedules) free_schedule(t);
+    d->schedules.clear();
 }
 
 static void free_scene(pt_device *d)
@@ -376,6 +423,7 @@ pt_status pt_device_destroy(pt_device *dev)
     (void)hipSetDevice(dev->index);
     (void)hipDeviceSynchronize();
     free_scene(dev);
+    drop_schedules(dev);
     (void)hipFree(dev->d_counters);
     for (auto &pr : dev->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : dev->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -608,6 +656,18 @@ pt_status pt_set_bvh_mode(pt_device *dev, int mode)
     return PT_OK;
 }
 
+pt_status pt_set_tile_schedule(pt_device *dev, int mode)
+{
+    clear_error();
+    if (!dev || mode < 0 || mode > 1) return set_error(PT_ERR_INVALID, "mode must be 0 (raster order) or 1 (cost-ordered)");
+    PT_HIP(hipSetDevice(dev->index));
+    PT_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(dev->mu);
+    dev->tile_schedule = mode;
+    drop_schedules(dev);
+    return PT_OK;
+}
+
 pt_status pt_set_traversal_mode(pt_device *dev, int mode)
 {
     clear_error();
@@ -659,12 +719,52 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.queue_entries = dev->queue_entries;
     P.sah = dev->sah ? 1 : 0;
     P.spec_pct = dev->spec_pct;
+    P.tile_order = nullptr; P.tile_cost = nullptr;
     if (dev->sah) P.stack_entries = (int)dev->sah_stack;
     P.queue_dwords = dev->packed_queue ? 1 : 2;
     P.n_mats = (int)dev->n_mats;
     // shading tables in LDS when they are small (Cornell box: 1.9 KB)
     P.shade_lds = (dev->n_tris * 48 + dev->n_mats * 48 + (size_t)dev->n_lights * 80) <= 16 * 1024 ? 1 : 0;
     return PT_OK;
+}
+
+// Finds (or makes) the schedule of this task geometry; null = render in raster order (feature off,
+// cache full of busy entries, or an allocation failed).  Caller holds dev->mu.
+static TileSchedule *schedule_for(pt_device *dev, const RenderParams &P, unsigned slots, hipStream_t hs)
+{
+    const int key[9] = {P.task_w, P.task_h, P.task_ox, P.task_oy, P.band_rows, P.band_ranks, P.band_rank, P.W, P.H};
+    dev->schedule_clock++;
+    for (TileSchedule *t : dev->schedules)
+        if (memcmp(t->key, key, sizeof key) == 0 && t->slots == slots) { t->stamp = dev->schedule_clock; return t; }
+    if (dev->schedules.size() >= 16) {
+        // evict the least recently used schedule whose last launch has finished
+        size_t victim = dev->schedules.size();
+        for (size_t i = 0; i < dev->schedules.size(); i++) {
+            TileSchedule *t = dev->schedules[i];
+            const bool idle = !t->used || hipEventQuery(t->last_use) == hipSuccess;
+            if (idle && (victim == dev->schedules.size() || t->stamp < dev->schedules[victim]->stamp)) victim = i;
+        }
+        (void)hipGetLastError();
+        if (victim == dev->schedules.size()) return nullptr;
+        free_schedule(dev->schedules[victim]);
+        dev->schedules.erase(dev->schedules.begin() + (long)victim);
+    }
+    std::unique_ptr<TileSchedule> t(new TileSchedule);
+    memcpy(t->key, key, sizeof key);
+    t->slots = slots;
+    t->stamp = dev->schedule_clock;
+    const size_t bytes = (size_t)slots * sizeof(uint32_t);
+    bool ok = hipMalloc((void **)&t->order, bytes) == hipSuccess && hipMalloc((void **)&t->cost, bytes) == hipSuccess &&
+              hipMalloc((void **)&t->sorted_cost, bytes) == hipSuccess && hipMalloc((void **)&t->iota, bytes) == hipSuccess;
+    if (ok) ok = hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t->temp_bytes, t->cost, t->sorted_cost, t->iota, t->order,
+                                                              (int)slots, 0, 32, hs) == hipSuccess;
+    if (ok) ok = hipMalloc(&t->temp, std::max<size_t>(t->temp_bytes, 16)) == hipSuccess;
+    if (ok) ok = hipEventCreateWithFlags(&t->last_use, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); free_schedule(t.release()); return nullptr; }
+    hipLaunchKernelGGL(dev::iota_kernel, dim3((slots + 255) / 256), dim3(256), 0, hs, t->iota, t->order, slots);
+    (void)hipMemsetAsync(t->cost, 0, bytes, hs);
+    dev->schedules.push_back(t.get());
+    return t.release();
 }
 
 static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream)
@@ -678,10 +778,20 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     size_t lds = lds_bytes(P, dev::kBlock, stage);
     hipStream_t hs = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev;
+    TileSchedule *sched = nullptr;
+    P.tile_order = nullptr; P.tile_cost = nullptr;
     {
         std::lock_guard<std::mutex> lk(dev->mu);
         if (!dev->free_events.empty()) { ev = dev->free_events.back(); dev->free_events.pop_back(); }
         else { PT_HIP(hipEventCreate(&ev.first)); PT_HIP(hipEventCreate(&ev.second)); }
+        // one wave slot per tile, and only worth it when the launch has several rounds of waves
+        if (dev->tile_schedule == 1 && blocks >= 1024) sched = schedule_for(dev, P, blocks * dev::kWavesPerBlock, hs);
+        if (sched) {
+            // a schedule is read and rewritten by its launches: order them across streams
+            if (sched->used && sched->last_stream != hs) PT_HIP(hipStreamWaitEvent(hs, sched->last_use, 0));
+            sched->used = true; sched->last_stream = hs;
+            P.tile_order = sched->order; P.tile_cost = sched->cost;
+        }
     }
     PT_HIP(hipEventRecord(ev.first, hs));
     if (walk == 3 && dev->sah_persistent) hipLaunchKernelGGL((dev::render_kernel_sah<0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
@@ -694,6 +804,12 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     else hipLaunchKernelGGL((dev::render_kernel<false, false, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     PT_HIP(hipGetLastError());
     PT_HIP(hipEventRecord(ev.second, hs));
+    if (sched) {
+        // next launch's order: tiles by this launch's cost, dearest first (stable, so ties keep raster order)
+        PT_HIP(hipcub::DeviceRadixSort::SortPairsDescending(sched->temp, sched->temp_bytes, sched->cost, sched->sorted_cost,
+                                                            sched->iota, sched->order, (int)sched->slots, 0, 32, hs));
+        PT_HIP(hipEventRecord(sched->last_use, hs));
+    }
     {
         std::lock_guard<std::mutex> lk(dev->mu);
         dev->pending.push_back(ev);

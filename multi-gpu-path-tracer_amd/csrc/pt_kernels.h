@@ -22,6 +22,8 @@ struct RenderParams {
     uint8_t *rgb;
     uint8_t *yuv;
     unsigned long long *counters;     // 5 x u64: paths, segments, box, tri, light
+    const uint32_t *tile_order;       // adaptive schedule: wave slot -> tile (a permutation), or null = raster order
+    uint32_t *tile_cost;              // adaptive schedule: shader-clock cost of each tile, written per wave, or null
     CameraBasis cam;
     double light_index_scale;         // (n-1) + 0.999999, hitable_list.h:24
     float light_weight;               // 1.0f / n, hitable_list.h:17

@@ -288,14 +288,34 @@ __device__ __forceinline__ void flush_counters(const RenderParams &P, const Path
     }
 }
 
+// Tile of this wave: its launch slot, or what the adaptive schedule assigns to that slot.
+__device__ __forceinline__ int wave_tile(const RenderParams &P, int tid)
+{
+    const int slot = blockIdx.x * kWavesPerBlock + tid / kWave;
+    return P.tile_order ? (int)P.tile_order[slot] : slot;
+}
+
+// Adaptive schedule: what this wave's tile cost, for next frame's order.  The cost is a trip count of
+// the wave's own loop, not a clock: s_memtime would make every later load "may be clobbered" for
+// the compiler and turn the walk's scalar loads into vector loads, and a count is reproducible.
+__device__ __forceinline__ void record_tile_cost(const RenderParams &P, int tid, uint32_t cost)
+{
+    if (P.tile_cost && (tid & (kWave - 1)) == 0) P.tile_cost[wave_tile(P, tid)] = cost;
+}
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+
 // Pixel of this lane: 8x8 tile per wave; in row-band mode (pt_render_bands_async) local row j is row
 // (j % band_rows) of this rank's (j / band_rows)-th band, band b of the frame (fb rows, 0 = top)
 // belonging to rank b % band_ranks.
 __device__ __forceinline__ bool lane_pixel(const RenderParams &P, int tid, int &x, int &y, int &pixel_index)
 {
     const int lane = tid & (kWave - 1);
-    const int wave = tid / kWave;
-    const int tile = blockIdx.x * kWavesPerBlock + wave;
+    const int tile = wave_tile(P, tid);
     const int tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
     const int i = tile_x * 8 + (lane & 7), j = tile_y * 8 + (lane >> 3);
     const bool in_task = (tile_y < P.tiles_y) && (i < P.task_w) && (j < P.task_h);

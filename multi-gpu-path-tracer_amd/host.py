@@ -294,6 +294,10 @@ class DevicePathTracer:
         if reload:
             self.reloadWorld()
 
+    def setTileSchedule(self, mode: int):
+        """0 raster order, 1 (default) tiles ordered by their cost in the previous launch of the same task."""
+        capi.check(capi.lib().pt_set_tile_schedule(self._h, mode))
+
     def setTraversalMode(self, mode: int):
         """0 auto, 1 per-lane walk, 2 wave-uniform walk / path mask (<= 64 inner nodes),
         3 wave-uniform walk / LDS stack (<= 4096 inner nodes)."""

@@ -186,3 +186,59 @@ def test_full_size_c2_properties(pt, box_scene, gpu_device):
     img = fb.rgb_host()
     assert img.mean() > 10 and img[:, :, 0].mean() != img[:, :, 1].mean()        # a lit, coloured Cornell box
     tr.close()
+
+
+@pytest.mark.parametrize("bvh", [0, 1])
+def test_cost_ordered_tile_schedule_never_changes_a_byte(pt, box_scene, gpu_device, bvh):
+    """pt_set_tile_schedule(1) reorders tiles from the previous launch's per-tile costs.  Every frame
+    (first = raster order, later = re-sorted each time) must equal the raster-order frame byte for
+    byte with identical work counters -- whole-frame tasks, single-launch row bands, and the same
+    task issued back to back on two streams (the schedule is shared state between those launches).
+    The framebuffer is cleared before every frame, so a tile dropped or duplicated by a broken
+    permutation would show."""
+    import torch
+    W, H, spp, depth = 1024, 512, 4, 4                       # 8192 tiles: above the 4096-tile threshold
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
+    if bvh:
+        tr.setBvhMode(1)
+    whole = pt.RenderTask(W, H, 0, 0)
+
+    def frame(launch):
+        fb.rgb.zero_(); fb.yuv.zero_()
+        torch.cuda.synchronize()
+        tr.resetCounters()
+        launch()
+        tr.waitForRenderTask()
+        return hashlib.sha256(fb.rgb_host().tobytes() + fb.yuv_host().tobytes()).hexdigest(), tr.readCounters()
+
+    tr.setTileSchedule(0)
+    want = frame(lambda: tr.renderTaskAsync(whole))
+    assert want[1]["paths"] == W * H * spp
+    tr.setTileSchedule(1)
+    for _ in range(4):
+        assert frame(lambda: tr.renderTaskAsync(whole)) == want
+
+    def bands():
+        tr.renderBandsAsync(8, 2, 0)
+        tr.renderBandsAsync(8, 2, 1)
+    for _ in range(3):
+        assert frame(bands) == want
+
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def two_streams():                                        # 2 x the same frame: counters double
+        tr.renderTaskAsync(whole, s1)
+        tr.renderTaskAsync(whole, s2)
+        tr.renderTaskAsync(whole, s1)
+        tr.renderTaskAsync(whole, s2)
+        tr.synchronizeStream(s1); tr.synchronizeStream(s2)
+    h, c = frame(two_streams)
+    assert h == want[0] and c["segments"] == 4 * want[1]["segments"] and c["tri_tests"] == 4 * want[1]["tri_tests"]
+    # more task geometries than the 16 tracked ones: the cache evicts or falls back, images stay put
+    for k in range(20):
+        t = pt.RenderTask(W - 8 * k, H, 0, 0)
+        fb.rgb.zero_(); fb.yuv.zero_()
+        tr.renderTaskAsync(t); tr.renderTaskAsync(t); tr.waitForRenderTask()
+    tr.setTileSchedule(0)
+    tr.close()
