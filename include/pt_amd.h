@@ -112,7 +112,7 @@ PT_API pt_status pt_set_bvh_mode(pt_device *dev, int mode);
  * frame-to-frame feedback (DSFL/DSDL adapt task rectangles from last frame's task times,
  * RenderManager.h:264-408) applied inside one GPU at tile granularity.  Pixels never depend on the
  * order (per-pixel seeds), so images are byte-identical in both modes.  Up to 16 task geometries
- * are tracked per device; launches of fewer than 4096 tiles always use raster order.          */
+ * are tracked per device; launches of fewer than 256 tiles always use raster order.          */
 PT_API pt_status pt_set_tile_schedule(pt_device *dev, int mode);
 
 /* Traversal schedule of the render kernel (same results and test counts, different order of

@@ -784,8 +784,8 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         std::lock_guard<std::mutex> lk(dev->mu);
         if (!dev->free_events.empty()) { ev = dev->free_events.back(); dev->free_events.pop_back(); }
         else { PT_HIP(hipEventCreate(&ev.first)); PT_HIP(hipEventCreate(&ev.second)); }
-        // one wave slot per tile, and only worth it when the launch has several rounds of waves
-        if (dev->tile_schedule == 1 && blocks >= 1024) sched = schedule_for(dev, P, blocks * dev::kWavesPerBlock, hs);
+        // one wave slot per tile; tiny launches are not worth a sort
+        if (dev->tile_schedule == 1 && blocks >= 64) sched = schedule_for(dev, P, blocks * dev::kWavesPerBlock, hs);
         if (sched) {
             // a schedule is read and rewritten by its launches: order them across streams
             if (sched->used && sched->last_stream != hs) PT_HIP(hipStreamWaitEvent(hs, sched->last_use, 0));
