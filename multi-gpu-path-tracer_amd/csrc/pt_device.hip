@@ -29,12 +29,18 @@ namespace pt {
 // ====================================================================== device code ==
 namespace dev {
 
+// Waves per SIMD the register allocator must make room for: 8 (64 VGPRs) costs a few spills in the
+// per-segment shading code, none in the traversal loops, and buys latency hiding (C2 80.6 -> 77.5 ms).
+#ifndef PT_RENDER_WAVES
+#define PT_RENDER_WAVES 8
+#endif
+
 // kWalk: 0 = per-lane two-phase walk, 1 = wave-uniform walk with a 64-bit path mask (<= 64 inner
 // nodes), 2 = wave-uniform walk with the per-lane LDS stack (medium trees), 3 = SAH tree walk.
 // render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
 // camera::ray_color (camera.h:49-83) flattened into a per-lane state machine.
 template <bool kLds, bool kPacked, int kWalk>
-__global__ __launch_bounds__(kBlock) void render_kernel(RenderParams P)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDER_WAVES, PT_RENDER_WAVES))) void render_kernel(RenderParams P)
 {
     extern __shared__ float4 lds_raw[];
     const int tid = threadIdx.x;
