@@ -120,6 +120,7 @@ def main():
                          "makes every ray test ~730k triangles)")
     ap.add_argument("--width", type=int, default=0, help="diagnostic: override the config's width")
     ap.add_argument("--height", type=int, default=0, help="diagnostic: override the config's height")
+    ap.add_argument("--spp", type=int, default=0, help="diagnostic: override the config's samples per pixel")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on a box with ONE GPU: every rank uses cuda:0 and the exchange runs "
                          "over gloo (RCCL needs one GPU per rank); checks the N > 1 code path, not its speed")
@@ -152,6 +153,9 @@ def main():
     if args.width or args.height:
         W, H = args.width or W, args.height or H
         desc += " [diagnostic size %dx%d]" % (W, H)
+    if args.spp:
+        spp = args.spp
+        desc += " [diagnostic spp %d]" % spp
     scene, camera = load_scene(pt, kind)
     cfg = pt.RendererConfig(samplesPerPixel=spp, recursionDepth=depth, gpuNumber=world,
                             resolution=pt.Resolution(W, H), showTasks=False)
@@ -222,7 +226,7 @@ def main():
         bytes_rank0 = algorithmic_bytes(cnt, my_pixels)
         achieved = bytes_rank0 / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic, traffic_src, valu = (None, None, None)
-        if world == 1 and not (args.width or args.height) and bvh == "reference":
+        if world == 1:                                   # matched on the workload string (size, spp, depth, tree)
             traffic, traffic_src, valu = measured_traffic(args.config, desc)
         out = {
             "metric": "ray-segments/s", "value": seg_per_s, "unit": "ray-segments/s",
