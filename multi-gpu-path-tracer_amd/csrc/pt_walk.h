@@ -81,6 +81,27 @@ __device__ __forceinline__ void load_tri(const TriIsect *tris, int slot, v3 &v0,
     e2 = mk3(b.z, b.w, c.x);
 }
 
+// Scene arrays as seen by the wave-uniform walks: never written while a render kernel runs, so they
+// are read through the CONSTANT address space.  That is what keeps their (wave-uniform) loads on the
+// scalar cache / in SGPRs: from a plain global pointer the compiler only emits s_load while it can
+// prove that nothing in the kernel may have clobbered the memory; an atomic or a store inside the
+// wave loop, or an s_memtime anywhere before, ends that proof and silently turns the walk's scalar
+// loads into vector loads (measured: C2 77 -> 96 ms with a work-queue atomic in the loop, 84 -> 92 ms
+// with one s_memtime at kernel entry).
+typedef float pt_f4 __attribute__((ext_vector_type(4)));
+struct ConstF4 {
+    const __attribute__((address_space(4))) pt_f4 *p;
+    __device__ __forceinline__ float4 operator[](int i) const { const pt_f4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ float scalar(int i, int c) const
+    {
+        return ((const __attribute__((address_space(4))) float *)(p + i))[c];
+    }
+};
+__device__ __forceinline__ ConstF4 as_constant(const void *q)
+{
+    ConstF4 r; r.p = (const __attribute__((address_space(4))) pt_f4 *)(q); return r;
+}
+
 // Scene accessors: the node and triangle arrays are read either from HBM (through L1/L2) or,
 // when the launch staged them, from LDS (ds_read_b128).
 template <bool kLds>
@@ -191,8 +212,8 @@ __device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 
     Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
     float tmax = tmax0;
     const v3 inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
-    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
-    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
+    const ConstF4 nodes = as_constant(P.nodes);
+    const ConstF4 tris = as_constant(P.tris);
     unsigned long long act = 1ull;                       // bit p: pair p is on this lane's path
     const int n_pairs = P.n_pairs;
     for (int p = 0; p < n_pairs; p++) {
@@ -213,7 +234,7 @@ __device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 
             } else if (__ballot(hit) != 0ull) {          // leaf child somebody hits
                 for (uint32_t k = link; k < link + cnt; k++) {
                     const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
-                    const float e2z = reinterpret_cast<const float *>(tris + 3 * k + 2)[0];
+                    const float e2z = tris.scalar(3 * k + 2, 0);
                     if (hit) {
                         float t, u, v;
                         n_tri++;
@@ -242,8 +263,8 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
     Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
     float tmax = tmax0;
     const v3 inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
-    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
-    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
+    const ConstF4 nodes = as_constant(P.nodes);
+    const ConstF4 tris = as_constant(P.tris);
     uint32_t next = 0;
     int sp = 0;
     bool walking = true;
@@ -282,7 +303,7 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
             if (cnt != 0 && __ballot(hit) != 0ull) {
                 for (uint32_t k = link; k < link + cnt; k++) {
                     const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
-                    const float e2z = reinterpret_cast<const float *>(tris + 3 * k + 2)[0];
+                    const float e2z = tris.scalar(3 * k + 2, 0);
                     if (hit) {
                         float t, u, v;
                         n_tri++;
