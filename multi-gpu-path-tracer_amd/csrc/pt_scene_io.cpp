@@ -153,6 +153,36 @@ int paeth(int a, int b, int c)
     return c;
 }
 
+// Reverses the PNG filters of one (sub-)image of pw x ph pixels in place; `p` holds ph rows of
+// 1 filter byte + `stride` data bytes.
+pt_status png_unfilter(uint8_t *p, size_t stride, int ph, size_t bpp)
+{
+    std::vector<uint8_t> prev(stride, 0);
+    for (int y = 0; y < ph; y++) {
+        uint8_t *line = p + (size_t)y * (stride + 1);
+        const int ft = line[0];
+        uint8_t *cur = line + 1;
+        if (ft > 4) return set_error(PT_ERR_IO, "bad PNG filter type");
+        for (size_t i = 0; i < stride; i++) {
+            int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int v = cur[i];
+            switch (ft) {
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b) / 2; break;
+            case 4: v += paeth(a, b, c); break;
+            default: break;
+            }
+            cur[i] = (uint8_t)v;
+        }
+        memcpy(prev.data(), cur, stride);
+    }
+    return PT_OK;
+}
+
+// Behaviour pinned against the reference's own third-party/stb_image.h (tests/test_oracle_pins.py,
+// oracle/_ref): every colour type, bit depths 1..16, all filters, Adam7 interlacing, palette and
+// colour-key transparency (tRNS), 16-bit samples reduced to their high byte.
 pt_status decode_png(const uint8_t *data, size_t len, int &w, int &h, int &channels,
                      std::vector<uint8_t> &out)
 {
@@ -161,7 +191,7 @@ pt_status decode_png(const uint8_t *data, size_t len, int &w, int &h, int &chann
     size_t pos = 8;
     int depth = 0, ctype = 0, interlace = 0;
     std::vector<uint8_t> idat, plte, trns;
-    bool have_ihdr = false;
+    bool have_ihdr = false, have_trns = false;
     while (pos + 12 <= len) {
         uint32_t clen = be32(data + pos);
         const uint8_t *type = data + pos + 4;
@@ -172,13 +202,13 @@ pt_status decode_png(const uint8_t *data, size_t len, int &w, int &h, int &chann
             depth = body[8]; ctype = body[9]; interlace = body[12];
             have_ihdr = true;
         } else if (!memcmp(type, "PLTE", 4)) plte.assign(body, body + clen);
-        else if (!memcmp(type, "tRNS", 4)) trns.assign(body, body + clen);
+        else if (!memcmp(type, "tRNS", 4)) { trns.assign(body, body + clen); have_trns = true; }
         else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + clen);
         else if (!memcmp(type, "IEND", 4)) break;
         pos += 12 + (size_t)clen;
     }
     if (!have_ihdr || w <= 0 || h <= 0) return set_error(PT_ERR_IO, "PNG without IHDR");
-    if (interlace) return set_error(PT_ERR_UNSUPPORTED, "interlaced PNG textures are not supported");
+    if (interlace > 1) return set_error(PT_ERR_IO, "bad PNG interlace method");
     int spp;   // samples per pixel in the file
     switch (ctype) {
     case 0: spp = 1; break;
@@ -188,60 +218,82 @@ pt_status decode_png(const uint8_t *data, size_t len, int &w, int &h, int &chann
     case 6: spp = 4; break;
     default: return set_error(PT_ERR_IO, "bad PNG colour type");
     }
-    if (!(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3))))
+    if (!(depth == 8 || (depth == 16 && ctype != 3) || (depth < 8 && (depth == 1 || depth == 2 || depth == 4) && (ctype == 0 || ctype == 3))))
         return set_error(PT_ERR_UNSUPPORTED, "unsupported PNG bit depth");
-    size_t bits_pp = (size_t)spp * (size_t)depth;
-    size_t stride = ((size_t)w * bits_pp + 7) / 8;
-    size_t bpp = std::max<size_t>(1, bits_pp / 8);
-    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    if (ctype == 3 && plte.empty()) return set_error(PT_ERR_IO, "palette PNG without PLTE");
+    if (have_trns) {                                            // stb_image.h: "tRNS with alpha" / "bad tRNS len"
+        if (ctype == 4 || ctype == 6) return set_error(PT_ERR_IO, "PNG tRNS chunk with an alpha colour type");
+        if (ctype == 3 && trns.size() > plte.size() / 3) return set_error(PT_ERR_IO, "bad PNG tRNS length");
+        if (ctype != 3 && trns.size() != (size_t)spp * 2) return set_error(PT_ERR_IO, "bad PNG tRNS length");
+    }
+    const size_t bits_pp = (size_t)spp * (size_t)depth;
+    const size_t bpp = std::max<size_t>(1, bits_pp / 8);
+    // sub-images: the whole picture, or the seven Adam7 passes {x0, y0, dx, dy}
+    static const int adam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const int whole[1][4] = {{0, 0, 1, 1}};
+    const int (*pass)[4] = interlace ? adam7 : whole;
+    const int n_pass = interlace ? 7 : 1;
+    size_t raw_need = 0;
+    for (int k = 0; k < n_pass; k++) {
+        const int pw = (w - pass[k][0] + pass[k][2] - 1) / pass[k][2], ph = (h - pass[k][1] + pass[k][3] - 1) / pass[k][3];
+        if (pw > 0 && ph > 0) raw_need += (((size_t)pw * bits_pp + 7) / 8 + 1) * (size_t)ph;
+    }
+    std::vector<uint8_t> raw(raw_need);
     uLongf rawlen = (uLongf)raw.size();
     int zr = uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size());
     if (zr != Z_OK || rawlen != raw.size()) return set_error(PT_ERR_IO, "PNG inflate failed");
-    // unfilter in place
-    std::vector<uint8_t> prev(stride, 0);
-    for (int y = 0; y < h; y++) {
-        uint8_t *line = raw.data() + (size_t)y * (stride + 1);
-        int ft = line[0];
-        uint8_t *cur = line + 1;
-        for (size_t i = 0; i < stride; i++) {
-            int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-            int v = cur[i];
-            switch (ft) {
-            case 0: break;
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) / 2; break;
-            case 4: v += paeth(a, b, c); break;
-            default: return set_error(PT_ERR_IO, "bad PNG filter type");
-            }
-            cur[i] = (uint8_t)v;
-        }
-        memcpy(prev.data(), cur, stride);
-    }
-    // expand to 8-bit samples, native channel count (palette -> RGB, or RGBA with tRNS)
-    channels = (ctype == 3) ? (trns.empty() ? 3 : 4) : spp;
-    out.resize((size_t)w * (size_t)h * (size_t)channels);
-    for (int y = 0; y < h; y++) {
-        const uint8_t *cur = raw.data() + (size_t)y * (stride + 1) + 1;
-        for (int x = 0; x < w; x++) {
-            uint8_t smp[4] = {0, 0, 0, 255};
-            for (int s = 0; s < spp; s++) {
-                if (depth == 8) smp[s] = cur[(size_t)x * spp + s];
-                else if (depth == 16) smp[s] = cur[((size_t)x * spp + s) * 2];          // high byte, as stb
-                else {
-                    size_t bit = (size_t)x * depth;
-                    int v = (cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1);
-                    smp[s] = (ctype == 3) ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1));
+    // samples at file precision, whole picture
+    std::vector<uint16_t> smp((size_t)w * (size_t)h * (size_t)spp);
+    size_t off = 0;
+    for (int k = 0; k < n_pass; k++) {
+        const int x0 = pass[k][0], y0 = pass[k][1], dx = pass[k][2], dy = pass[k][3];
+        const int pw = (w - x0 + dx - 1) / dx, ph = (h - y0 + dy - 1) / dy;
+        if (pw <= 0 || ph <= 0) continue;
+        const size_t stride = ((size_t)pw * bits_pp + 7) / 8;
+        pt_status st = png_unfilter(raw.data() + off, stride, ph, bpp);
+        if (st != PT_OK) return st;
+        for (int y = 0; y < ph; y++) {
+            const uint8_t *cur = raw.data() + off + (size_t)y * (stride + 1) + 1;
+            for (int x = 0; x < pw; x++) {
+                uint16_t *o = &smp[(((size_t)(y0 + y * dy)) * (size_t)w + (size_t)(x0 + x * dx)) * (size_t)spp];
+                for (int c = 0; c < spp; c++) {
+                    if (depth == 8) o[c] = cur[(size_t)x * spp + c];
+                    else if (depth == 16) o[c] = (uint16_t)((cur[((size_t)x * spp + c) * 2] << 8) | cur[((size_t)x * spp + c) * 2 + 1]);
+                    else {
+                        const size_t bit = (size_t)x * depth;
+                        o[c] = (uint16_t)((cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1));
+                    }
                 }
             }
-            uint8_t *o = &out[((size_t)y * w + x) * channels];
-            if (ctype == 3) {
-                size_t idx = smp[0];
-                for (int k = 0; k < 3; k++) o[k] = (idx * 3 + k < plte.size()) ? plte[idx * 3 + k] : 0;
-                if (channels == 4) o[3] = idx < trns.size() ? trns[idx] : 255;
-            } else {
-                for (int k = 0; k < channels; k++) o[k] = smp[k];
+        }
+        off += (stride + 1) * (size_t)ph;
+    }
+    // expand to 8-bit samples: palette -> RGB (RGBA with tRNS); colour key -> extra alpha channel;
+    // grey below 8 bits scaled to 0..255; 16-bit -> high byte
+    const bool key = have_trns && ctype != 3;
+    channels = (ctype == 3) ? (have_trns ? 4 : 3) : spp + (key ? 1 : 0);
+    out.resize((size_t)w * (size_t)h * (size_t)channels);
+    uint16_t keyv[3] = {0, 0, 0};
+    if (key) for (int c = 0; c < spp; c++) {
+        const uint16_t v = (uint16_t)((trns[2 * c] << 8) | trns[2 * c + 1]);
+        keyv[c] = depth == 16 ? v : (uint16_t)(v & 255);      // stb_image.h keeps the low byte of a key below 16 bits
+    }
+    const int scale = depth < 8 ? 255 / ((1 << depth) - 1) : 1;
+    for (size_t px = 0; px < (size_t)w * (size_t)h; px++) {
+        const uint16_t *in = &smp[px * (size_t)spp];
+        uint8_t *o = &out[px * (size_t)channels];
+        if (ctype == 3) {
+            const size_t idx = in[0];
+            for (int c = 0; c < 3; c++) o[c] = (idx * 3 + c < plte.size()) ? plte[idx * 3 + c] : 0;   // past the palette: undefined in stb
+            if (channels == 4) o[3] = idx < trns.size() ? trns[idx] : 255;
+        } else {
+            bool is_key = key;
+            for (int c = 0; c < spp; c++) {
+                o[c] = depth == 16 ? (uint8_t)(in[c] >> 8) : (uint8_t)(in[c] * scale);
+                // the key is compared at 16 bits for 16-bit files, on the scaled 8-bit value otherwise
+                if (key) is_key = is_key && (depth == 16 ? in[c] == keyv[c] : o[c] == (uint8_t)(keyv[c] * scale));
             }
+            if (key) o[spp] = is_key ? 0 : 255;
         }
     }
     return PT_OK;

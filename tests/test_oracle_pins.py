@@ -5,6 +5,8 @@ oracle is pinned by (1) the structural statistics the survey-stage probe of the 
 own headers recorded in BASELINE.md section 3 / SURVEY.md section 6, (2) single-ray
 known-answer cases derived by hand from the reference's source text, and (3) committed golden
 outputs (regression pin).  Image-level parity with the CUDA renderer stays "unpinned".
+The one buildable piece of the reference, its vendored stb_image.h (oracle/_ref), pins the product's
+PNG texture decoder at the end of this file.
 """
 import os
 
@@ -153,3 +155,63 @@ def test_triangle_hit_known_answers(ob):
     small = [0, 0, 0, 1e-4, 0, 0, 0, 1e-4, 0]                      # det = 1e-8 * dir.z scale
     assert ob.tri_hit(small, [2e-5, 2e-5, 1], [0, 0, -0.5])[0] == 0            # |det| = 5e-9 < 1e-8
     assert ob.tri_hit(small, [2e-5, 2e-5, 1], [0, 0, -2.0])[0] == 1            # |det| = 2e-8
+
+
+# ---- the one part of the reference that IS buildable here: its vendored texture decoder ------------
+
+def _reference_texels(meta, px):
+    """What SceneLoader::loadTextureFromFile makes of stb_image's output (HostScene.cpp:36-46): it copies
+    width*height*3 bytes whatever the channel count, so 4-channel data is read mis-strided and data with
+    fewer than 3 channels is read out of bounds (the product refuses those)."""
+    w, h, comp = (int(v) for v in meta)
+    if w < 0 or comp < 3:
+        return None
+    return px[:w * h * 3].reshape(h, w, 3)
+
+
+def test_png_decoder_is_pinned_to_the_references_stb_image(pt, tmp_path):
+    """Product PNG decoder (csrc/pt_scene_io.cpp) vs the reference's own third-party/stb_image.h:
+    46 synthetic PNGs (every colour type, bit depths 1..16, all five filters, Adam7, palette and
+    colour-key tRNS, split IDAT), 8 malformed files, and the texture of cornell_duck.glb.  The expected
+    outputs are committed (tests/golden/stb_png_vectors.npz, made by make_stb_vectors.py from
+    oracle/_ref); where oracle/_ref exists (the reference is present or a prebuilt copy travelled) the
+    real decoder is run again and must still give the committed bytes."""
+    import hashlib
+    import pngkit
+    from oracle import ref_stb
+    g = np.load(os.path.join(GOLD, "stb_png_vectors.npz"))
+    names = [str(n) for n in g["names"]]
+    assert len(names) >= 50
+    live = ref_stb.available()
+    p = tmp_path / "t.glb"
+    n_ok = n_refused = 0
+    for name in names:
+        png = g["png_" + name].tobytes()
+        meta = g["meta_" + name]
+        px = g["px_" + name] if "px_" + name in g else None
+        if live:                                                        # the committed vector IS the reference's output
+            r = ref_stb.load_from_memory(png)
+            assert (r is None) == (meta[0] < 0), name
+            if r is not None:
+                assert list(r[:3]) == list(meta) and np.array_equal(r[3], px), name
+        want = _reference_texels(meta, px)
+        p.write_bytes(pngkit.glb_with_texture(png))
+        if want is None:
+            with pytest.raises(RuntimeError):
+                pt.SceneLoader().load(str(p))
+            n_refused += 1
+        else:
+            (tex,) = pt.SceneLoader().load(str(p)).textures
+            assert tex.shape == want.shape and np.array_equal(tex.astype(np.uint8), want), name
+            assert np.array_equal(tex, tex.astype(np.uint8))           # texels are the integers 0..255 as floats
+            n_ok += 1
+    assert n_ok >= 25 and n_refused >= 20 and n_ok + n_refused == len(names)
+    # the duck's real texture
+    duck = pt.SceneLoader().load(os.path.join(ROOT, "models", "cornell_duck.glb"))
+    (tex,) = duck.textures
+    w, h, comp = (int(v) for v in g["duck_meta"])
+    assert tex.shape == (h, w, 3) and comp == 3
+    assert hashlib.sha256(tex.astype(np.uint8).tobytes()).digest() == g["duck_sha256"].tobytes()
+    if live:
+        r = ref_stb.load_from_memory(pngkit.glb_images(os.path.join(ROOT, "models", "cornell_duck.glb"))[0])
+        assert np.array_equal(r[3], tex.astype(np.uint8).reshape(-1))
