@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--width", type=int, default=0, help="diagnostic: override the config's width")
     ap.add_argument("--height", type=int, default=0, help="diagnostic: override the config's height")
     ap.add_argument("--spp", type=int, default=0, help="diagnostic: override the config's samples per pixel")
+    ap.add_argument("--walk", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="diagnostic: pt_set_traversal_mode (0 auto, 1 per-lane, 2 wave-uniform mask, 3 wave-uniform stack)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on a box with ONE GPU: every rank uses cuda:0 and the exchange runs "
                          "over gloo (RCCL needs one GPU per rank); checks the N > 1 code path, not its speed")
@@ -167,6 +169,9 @@ def main():
                            bvh_mode=1 if bvh == "sah" else 0)
     upload_s = time.perf_counter() - t_up
     mgr.tracer.setTileSchedule(args.tile_schedule)
+    if args.walk:
+        mgr.tracer.setTraversalMode(args.walk)
+        desc += " [diagnostic walk %d]" % args.walk
 
     if args.share_of > 1 and world == 1:
         # what one rank of an N-GPU run computes, measured on this GPU alone (no gather)
@@ -240,6 +245,7 @@ def main():
             "segments_per_frame": total["segments"] // args.steps,
             "scene_upload_s": upload_s,
             "segments_per_path": total["segments"] / max(total["paths"], 1),
+            "tests_per_segment": {k: total[k] / max(total["segments"], 1) for k in ("box_tests", "tri_tests", "light_tests")},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

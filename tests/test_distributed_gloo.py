@@ -53,7 +53,8 @@ def _worker(rank, world, port, W, H, band, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,W,H,band", [(2, 64, 36, 8), (3, 48, 50, 4), (2, 32, 6, 8)])
+@pytest.mark.parametrize("world,W,H,band", [(2, 64, 36, 8), (3, 48, 50, 4), (2, 32, 6, 8),
+                                              (8, 1920, 1080, 8)])     # the scaling run: 135 bands, ranks own 17 or 16
 def test_gather_frame_gloo(tmp_path, world, W, H, band):
     out = tmp_path / "result.txt"
     mp.spawn(_worker, args=(world, _free_port(), W, H, band, str(out)), nprocs=world, join=True)
