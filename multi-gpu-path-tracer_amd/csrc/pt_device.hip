@@ -288,6 +288,7 @@ using namespace pt;
 struct TileSchedule {
     int key[9];
     unsigned slots = 0;
+    void *base = nullptr;         // one stream-ordered allocation, carved into the buffers below
     uint32_t *order = nullptr, *cost = nullptr, *sorted_cost = nullptr, *iota = nullptr;
     void *temp = nullptr;
     size_t temp_bytes = 0;
@@ -352,10 +353,11 @@ static int choose_walk(const pt_device *d)
     return mask_ok ? 1 : (stack_ok ? 2 : 0);
 }
 
-static void free_schedule(TileSchedule *t)
+// `hs` != null: stream-ordered free (the schedule's last launch has finished); null: plain free after
+// a device synchronisation.
+static void free_schedule(TileSchedule *t, hipStream_t hs = nullptr, bool async = false)
 {
-    (void)hipFree(t->order); (void)hipFree(t->cost); (void)hipFree(t->sorted_cost); (void)hipFree(t->iota);
-    (void)hipFree(t->temp);
+    if (t->base) { if (async) (void)hipFreeAsync(t->base, hs); else (void)hipFree(t->base); }
     if (t->last_use) (void)hipEventDestroy(t->last_use);
     delete t;
 }
@@ -752,21 +754,26 @@ static TileSchedule *schedule_for(pt_device *dev, const RenderParams &P, unsigne
         }
         (void)hipGetLastError();
         if (victim == dev->schedules.size()) return nullptr;
-        free_schedule(dev->schedules[victim]);
+        free_schedule(dev->schedules[victim], hs, true);
         dev->schedules.erase(dev->schedules.begin() + (long)victim);
     }
     std::unique_ptr<TileSchedule> t(new TileSchedule);
     memcpy(t->key, key, sizeof key);
     t->slots = slots;
     t->stamp = dev->schedule_clock;
-    const size_t bytes = (size_t)slots * sizeof(uint32_t);
-    bool ok = hipMalloc((void **)&t->order, bytes) == hipSuccess && hipMalloc((void **)&t->cost, bytes) == hipSuccess &&
-              hipMalloc((void **)&t->sorted_cost, bytes) == hipSuccess && hipMalloc((void **)&t->iota, bytes) == hipSuccess;
-    if (ok) ok = hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t->temp_bytes, t->cost, t->sorted_cost, t->iota, t->order,
-                                                              (int)slots, 0, 32, hs) == hipSuccess;
-    if (ok) ok = hipMalloc(&t->temp, std::max<size_t>(t->temp_bytes, 16)) == hipSuccess;
-    if (ok) ok = hipEventCreateWithFlags(&t->last_use, hipEventDisableTiming) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); free_schedule(t.release()); return nullptr; }
+    // One stream-ordered allocation (hipMallocAsync: no device-wide synchronisation, so scheduling
+    // policies that move their rectangles every frame, DSFL / DSDL, can afford a fresh schedule per launch)
+    const size_t bytes = (((size_t)slots * sizeof(uint32_t)) + 255) & ~(size_t)255;
+    bool ok = hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t->temp_bytes, t->cost, t->sorted_cost, t->iota, t->order,
+                                                           (int)slots, 0, 32, hs) == hipSuccess;
+    if (ok) ok = hipMallocAsync(&t->base, 4 * bytes + std::max<size_t>(t->temp_bytes, 256), hs) == hipSuccess;
+    if (ok) {
+        uint8_t *b = (uint8_t *)t->base;
+        t->order = (uint32_t *)b; t->cost = (uint32_t *)(b + bytes); t->sorted_cost = (uint32_t *)(b + 2 * bytes);
+        t->iota = (uint32_t *)(b + 3 * bytes); t->temp = b + 4 * bytes;
+        ok = hipEventCreateWithFlags(&t->last_use, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) { (void)hipGetLastError(); free_schedule(t.release(), hs, true); return nullptr; }
     hipLaunchKernelGGL(dev::iota_kernel, dim3((slots + 255) / 256), dim3(256), 0, hs, t->iota, t->order, slots);
     (void)hipMemsetAsync(t->cost, 0, bytes, hs);
     dev->schedules.push_back(t.get());
