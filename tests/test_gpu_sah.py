@@ -18,29 +18,34 @@ def _tracer(pt, scene, cam, W=8, H=8, spp=1, depth=1, sah=True):
     return tr, fb
 
 
-@pytest.mark.parametrize("name,n", [("box", 200000), ("duck", 200000)])
+@pytest.mark.parametrize("name,n", [("box", 10_000_000), ("duck", 10_000_000)])
 def test_sah_closest_hits_equal_reference_traversal(pt, box_scene, duck_scene, gpu_device, name, n):
-    """Same rays through the reference-topology walk and the SAH walk on the GPU: t and face must
-    agree (ties included: both resolve them by the reference's visit order)."""
+    """SURVEY 8f-1 parity gate: identical closest-hit triangle and t as the reference-topology walk on
+    1e7 random rays (origins inside the scene's bounds, every 13th direction in a coordinate plane).
+    Both walks run on the GPU; ties resolve by the reference's visit order in both."""
     scene, cam = (box_scene, BOX_CAMERA) if name == "box" else (duck_scene, DUCK_CAMERA)
     rng = np.random.default_rng(11)
     tris = scene.triangles
     lo = np.min([tris[v]["position"].min(axis=0) for v in ("v0", "v1", "v2")], axis=0)
     hi = np.max([tris[v]["position"].max(axis=0) for v in ("v0", "v1", "v2")], axis=0)
-    org = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
-    dirs = rng.standard_normal((n, 3)).astype(np.float32)
-    dirs[::13, 2] = 0.0
     ref_tr, _ = _tracer(pt, scene, cam, sah=False)
-    t_ref, f_ref = ref_tr.katClosestHit(org, dirs)
-    ref_tr.close()
     sah_tr, _ = _tracer(pt, scene, cam, sah=True)
-    t_sah, f_sah = sah_tr.katClosestHit(org, dirs)
+    mismatch = hits = 0
+    chunk = 2_000_000
+    for _ in range(n // chunk):
+        org = rng.uniform(lo, hi, (chunk, 3)).astype(np.float32)
+        dirs = rng.standard_normal((chunk, 3), dtype=np.float32)
+        dirs[::13, 2] = 0.0
+        t_ref, f_ref = ref_tr.katClosestHit(org, dirs)
+        t_sah, f_sah = sah_tr.katClosestHit(org, dirs)
+        same = (t_ref.view(np.uint32) == t_sah.view(np.uint32)) & (f_ref == f_sah)
+        mismatch += int((~same).sum())
+        hits += int((f_ref >= 0).sum())
+    ref_tr.close()
     sah_tr.close()
-    same = (t_ref.view(np.uint32) == t_sah.view(np.uint32)) & (f_ref == f_sah)
-    mismatch = int((~same).sum())
     print("%s: %d / %d rays differ" % (name, mismatch, n))
     assert mismatch <= n // 20000          # <= 0.005 %: only grazing-ray artefacts may differ
-    assert (f_ref >= 0).mean() > 0.5
+    assert hits > n // 2
 
 
 @pytest.mark.parametrize("name,W,H,spp,depth", [("box", 160, 90, 8, 8), ("duck", 96, 54, 3, 8)])
