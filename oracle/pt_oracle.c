@@ -102,6 +102,14 @@ static inline f3 normalize3(f3 v)
  */
 void ptor_sincosf(float x, float *s_out, float *c_out)
 {
+#ifdef PTOR_CUDA_LIKE
+    /* measurement variant only (oracle/Makefile: libpt_oracle_cudalike.so): a libm's sin/cos, and the
+     * file is compiled with FMA contraction on -- the two freedoms the CUDA build of the reference
+     * takes and this contract does not.  tests/test_oracle_pins.py uses it to MEASURE how far such
+     * arithmetic moves the image (SURVEY 8c tier T3); nothing is checked against it bit-for-bit. */
+    *s_out = sinf(x); *c_out = cosf(x);
+    return;
+#endif
     float kf = (float)(int)(x * 0.636619772f + 0.5f);   /* nearest multiple of pi/2, x >= 0 */
     int   k  = (int)kf;
     float r  = fmaf(-kf, 1.57079637e+0f, x);            /* pi/2 hi (0x3FC90FDB)            */
@@ -126,6 +134,9 @@ void ptor_sincosf(float x, float *s_out, float *c_out)
 }
 static inline float ptor_tanf(float x)
 {
+#ifdef PTOR_CUDA_LIKE
+    return tanf(x);
+#endif
     float s, c; ptor_sincosf(x, &s, &c); return s / c;
 }
 
