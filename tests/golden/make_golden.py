@@ -28,6 +28,9 @@ CASES = [
     ("box_160x90_8spp_8b", "box", BOX_CAMERA, 160, 90, 8, 8),
     ("duck_64x36_2spp_4b", "duck", DUCK_CAMERA, 64, 36, 2, 4),
     ("duck_96x54_3spp_8b", "duck", DUCK_CAMERA, 96, 54, 3, 8),
+    # BASELINE.json configs[0] (C1, the CPU-runnable case) and the survey's larger duck fixture
+    ("box_400x400_16spp_4b", "box", BOX_CAMERA, 400, 400, 16, 4),
+    ("duck_160x90_4spp_8b", "duck", DUCK_CAMERA, 160, 90, 4, 8),
 ]
 
 

@@ -15,7 +15,9 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 @pytest.mark.parametrize("name,scene", [("box_64x64_4spp_4b", "box"), ("box_160x90_8spp_8b", "box"),
-                                        ("duck_64x36_2spp_4b", "duck"), ("duck_96x54_3spp_8b", "duck")])
+                                        ("duck_64x36_2spp_4b", "duck"), ("duck_96x54_3spp_8b", "duck"),
+                                        ("box_400x400_16spp_4b", "box"),      # BASELINE.json configs[0] (C1)
+                                        ("duck_160x90_4spp_8b", "duck")])
 def test_hip_path_reproduces_golden_fixtures(pt, box_scene, duck_scene, gpu_device, name, scene):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     W, H, spp, depth = [int(v) for v in g["params"]]

@@ -69,7 +69,9 @@ def test_duck_statistics_match_reference_probe(duck_oracle):
 
 
 @pytest.mark.parametrize("name,scene", [("box_64x64_4spp_4b", "box"), ("box_160x90_8spp_8b", "box"),
-                                        ("duck_64x36_2spp_4b", "duck"), ("duck_96x54_3spp_8b", "duck")])
+                                        ("duck_64x36_2spp_4b", "duck"), ("duck_96x54_3spp_8b", "duck"),
+                                        ("box_400x400_16spp_4b", "box"),      # BASELINE.json configs[0] (C1)
+                                        ("duck_160x90_4spp_8b", "duck")])
 def test_oracle_reproduces_golden_images(box_oracle, duck_oracle, name, scene):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     W, H, spp, depth = [int(v) for v in g["params"]]
