@@ -110,8 +110,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
 // are walking -- until at least half of those that were walking have finished -- and (3) shading
 // the finished ones, while the stragglers keep their traversal state (pair, LDS stack, closest
 // hit) across trips.  Per ray the sequence of tests is exactly traverse_sah's.
-template <int kDummy>
-__global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P)
+__device__ __forceinline__ void render_sah_body(const RenderParams &P)
 {
     extern __shared__ float4 lds_raw[];
     const int tid = threadIdx.x;
@@ -162,6 +161,13 @@ __global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P)
     flush_counters(P, L, lane);
     record_tile_cost(P, tid, cost);
 }
+
+// Two builds of the same body.  Its natural allocation is 93 VGPRs (5 waves/SIMD).  Scenes whose tree
+// and triangles stay in cache are issue-bound and gain from a sixth wave even at the price of a few
+// spills (C3 143 -> 136 ms); the 1 GB terrain is bound by memory latency per dependent step and loses
+// to the spills (C4 84 -> 88 ms), so it keeps the natural allocation.
+__global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P) { render_sah_body(P); }
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_sah6(RenderParams P) { render_sah_body(P); }
 
 // ---- known-answer kernels (bit-exactness contract) -----------------------------------
 __global__ void kat_arith_kernel(int op, const float *a, const float *b, float *o0, float *o1, size_t n)
@@ -807,7 +813,11 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         }
     }
     PT_HIP(hipEventRecord(ev.first, hs));
-    if (walk == 3 && dev->sah_persistent) hipLaunchKernelGGL((dev::render_kernel_sah<0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    if (walk == 3 && dev->sah_persistent) {
+        const size_t scene_bytes = dev->n_pairs * sizeof(NodePair) + dev->n_tris * sizeof(TriIsect);
+        if (scene_bytes <= ((size_t)64 << 20)) hipLaunchKernelGGL(dev::render_kernel_sah6, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+        else hipLaunchKernelGGL(dev::render_kernel_sah, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    }
     else if (walk == 3) hipLaunchKernelGGL((dev::render_kernel<false, true, 3>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (walk == 1) hipLaunchKernelGGL((dev::render_kernel<false, true, 1>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (walk == 2) hipLaunchKernelGGL((dev::render_kernel<false, true, 2>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
