@@ -56,7 +56,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
 
     PathState L;
     path_init(L, P, pixel_index);
-    bool alive = in_frame && P.depth > 0;     // depth 0: ray_color returns (0,0,0) untraced
+    bool alive = in_frame && P.depth > 0;     // depth 0: ray_color returns (0,0,0) untraced ...
+    if (in_frame && P.depth == 0) L.n_paths = (uint32_t)P.spp;      // ... for camera rays that are still generated (:84-87)
 #ifdef PT_STAMPS
     // diagnostic build only (tools/stamps.sh): shader-clock cycles spent inside the traversal vs the
     // whole wave loop, summed per wave into counters[5..7]; never compiled into the shipped library
@@ -126,6 +127,7 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
     SahWalk W;
     sah_begin(W, mk3(1.0f, 1.0f, 1.0f), 0.0f);
     bool alive = in_frame && P.depth > 0;
+    if (in_frame && P.depth == 0) L.n_paths = (uint32_t)P.spp;      // camera rays are generated, then ray_color returns untraced
     bool walking = false;
     uint32_t cost = 0;                                    // wave-uniform: micro-step trips + 8 per outer trip
     while (true) {

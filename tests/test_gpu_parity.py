@@ -262,6 +262,15 @@ def test_c5_parameters_small_frame(pt, box_scene, box_oracle, gpu_device):
     _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, 32, 16, 1024, 16), ref)
 
 
+def test_depth_zero_counts_camera_rays_and_renders_black(pt, box_scene, box_oracle, gpu_device):
+    """recursionDepth 0: camera rays are generated (paths = pixels x spp), nothing is traced, the frame is
+    black (camera.h:49-83 returns (0,0,0)).  Found by tools/fuzz_parity.py: the kernels used to report 0 paths."""
+    ref = box_oracle.render(BOX_CAMERA, 24, 16, 3, 0)
+    assert ref[2]["paths"] == 24 * 16 * 3 and ref[2]["segments"] == 0 and not ref[0].any()
+    for mode in (0, 1, 2):
+        _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, 24, 16, 3, 0, mode=mode), ref)
+
+
 def _random_scene(pt, seed):
     """Random triangle soup in [-10,10]^3 with random materials, 1-3 emissive triangles, random UVs
     and (sometimes) a texture: nothing about it is tuned to any walk's fast path."""

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""On the GPU box: randomized parity campaign, HIP path vs the CPU oracle, bit-exact (bytes + counters).
+Random triangle soups (tests/test_gpu_parity.py::_random_scene), random even frame sizes, spp, depth,
+walk schedule, tile schedule, and a random way of covering the frame: one task, a grid of rectangular
+tasks with ragged edges, or single-launch row bands of a random number of ranks.
+usage: python tools/fuzz_parity.py [first_seed] [count]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+pt = importlib.import_module("multi-gpu-path-tracer_amd")
+from oracle import binding as ob  # noqa: E402  (test infrastructure: this is a checker, not the product)
+import test_gpu_parity as tgp  # noqa: E402
+
+
+def one(seed):
+    rng = np.random.default_rng(10_000 + seed)
+    tris, mats, texs, cam = tgp._random_scene(pt, seed)
+    W, H = 2 * int(rng.integers(4, 49)), 2 * int(rng.integers(4, 33))
+    spp, depth = int(rng.integers(1, 7)), int(rng.integers(0, 10))
+    scene = pt.HostScene.from_arrays(tris, mats, texs)
+    ref = ob.OracleScene(tris, mats, texs).render(cam, W, H, spp, depth, threads=8)
+    info = pt.host_bvh_build(tris)[0]
+    modes = [0, 1, 3] + ([2] if info["nodes"] - info["leaves"] <= 64 else [])
+    mode = int(rng.choice(modes))
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, pt.CameraConfig(cam[0], cam[1], cam[2], cam[3]))
+    tr.setTraversalMode(mode)
+    tr.setTileSchedule(int(rng.integers(0, 2)))
+    cover = int(rng.integers(0, 3))
+    frames = int(rng.integers(1, 4))                      # later frames run in cost order
+    for _ in range(frames):
+        fb.rgb.zero_(); fb.yuv.zero_()
+        tr.resetCounters()
+        if cover == 0:
+            tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0))
+        elif cover == 1:
+            xs = sorted(set([0, W] + [int(v) for v in rng.integers(1, W, int(rng.integers(0, 4)))]))
+            ys = sorted(set([0, H] + [int(v) for v in rng.integers(1, H, int(rng.integers(0, 4)))]))
+            for y0, y1 in zip(ys[:-1], ys[1:]):
+                for x0, x1 in zip(xs[:-1], xs[1:]):
+                    tr.renderTaskAsync(pt.RenderTask(x1 - x0, y1 - y0, x0, y0))
+        else:
+            band, world = 2 * int(rng.integers(1, 9)), int(rng.integers(1, 6))
+            for r in range(world):
+                tr.renderBandsAsync(band, world, r)
+        tr.waitForRenderTask()
+        got = (fb.rgb_host().copy(), fb.yuv_host().copy(), tr.readCounters())
+        tgp._assert_same(got, ref)
+    tr.close()
+    return W, H, spp, depth, mode, cover, frames, len(tris)
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    t0 = time.time()
+    for seed in range(first, first + count):
+        try:
+            desc = one(seed)
+        except Exception as e:          # noqa: BLE001
+            print("FAIL seed", seed, repr(e)[:400], flush=True)
+            sys.exit(1)
+        if seed % 10 == 0:
+            print("seed %d ok %s  (%.0f s)" % (seed, desc, time.time() - t0), flush=True)
+    print("all %d cases bit-exact" % count)
+
+
+if __name__ == "__main__":
+    main()
