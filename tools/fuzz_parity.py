@@ -19,6 +19,11 @@ from oracle import binding as ob  # noqa: E402  (test infrastructure: this is a 
 import test_gpu_parity as tgp  # noqa: E402
 
 
+SAH_STATS = {"cases": 0, "cases_differ": 0, "bytes": 0, "bytes_differ": 0} if "--sah" in sys.argv else None
+if SAH_STATS is not None:
+    sys.argv.remove("--sah")
+
+
 def one(seed):
     rng = np.random.default_rng(10_000 + seed)
     tris, mats, texs, cam = tgp._random_scene(pt, seed)
@@ -54,6 +59,16 @@ def one(seed):
         got = (fb.rgb_host().copy(), fb.yuv_host().copy(), tr.readCounters())
         tgp._assert_same(got, ref)
     tr.close()
+    # statistic, not a gate: the opt-in SAH tree is not the reference's traversal
+    if SAH_STATS is not None:
+        fb2 = pt.Framebuffer(pt.Resolution(W, H))
+        tr2 = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb2, pt.CameraConfig(cam[0], cam[1], cam[2], cam[3]))
+        tr2.setBvhMode(1)
+        tr2.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr2.waitForRenderTask()
+        diff = int((fb2.rgb_host() != ref[0]).sum())
+        SAH_STATS["cases"] += 1; SAH_STATS["bytes"] += ref[0].size
+        SAH_STATS["cases_differ"] += diff > 0; SAH_STATS["bytes_differ"] += diff
+        tr2.close()
     return W, H, spp, depth, mode, cover, frames, len(tris)
 
 
@@ -70,6 +85,8 @@ def main():
         if seed % 10 == 0:
             print("seed %d ok %s  (%.0f s)" % (seed, desc, time.time() - t0), flush=True)
     print("all %d cases bit-exact" % count)
+    if SAH_STATS is not None:
+        print("SAH tree vs oracle images:", SAH_STATS)
 
 
 if __name__ == "__main__":
