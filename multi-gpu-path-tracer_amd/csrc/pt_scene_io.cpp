@@ -153,6 +153,10 @@ int paeth(int a, int b, int c)
     return c;
 }
 
+} // namespace
+pt_status decode_jpeg(const uint8_t *data, size_t len, int &w, int &h, int &channels, std::vector<uint8_t> &out);   // pt_jpeg.cpp
+namespace {
+
 // Reverses the PNG filters of one (sub-)image of pw x ph pixels in place; `p` holds ph rows of
 // 1 filter byte + `stride` data bytes.
 pt_status png_unfilter(uint8_t *p, size_t stride, int ph, size_t bpp)
@@ -457,7 +461,9 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
         if (!view_span(bv->integer(-1), ptr, len, stride)) return set_error(PT_ERR_IO, "bad image bufferView");
         int w = 0, h = 0, ch = 0;
         std::vector<uint8_t> px;
-        pt_status st = decode_png(ptr, len, w, h, ch, px);
+        // stb_image tries PNG first and JPEG later (stb_image.h stbi__load_main); GLB images are one of the two
+        const bool is_jpeg = len >= 3 && ptr[0] == 0xff && ptr[1] == 0xd8 && ptr[2] == 0xff;
+        pt_status st = is_jpeg ? decode_jpeg(ptr, len, w, h, ch, px) : decode_png(ptr, len, w, h, ch, px);
         if (st != PT_OK) return st;
         // HostScene.cpp:36-46: the copy loop assumes 3 bytes per pixel whatever the file has.
         if (ch < 3) return set_error(PT_ERR_UNSUPPORTED, "textures with fewer than 3 channels are read out of bounds by the reference (HostScene.cpp:38-46)");

@@ -4,7 +4,7 @@
  * third-party/stb_image.h (used by SceneLoader::loadTextureFromFile, HostScene.cpp:6-7,19-30).
  * This translation unit does nothing but instantiate that header FROM WHERE IT LIES under
  * /root/reference (-I$(REFERENCE); nothing is copied into this repo) so that the product's own PNG
- * decoder (csrc/pt_scene_io.cpp) can be pinned against the real thing.  Built by oracle/Makefile
+ * and JPEG decoders (csrc/pt_scene_io.cpp, csrc/pt_jpeg.cpp) can be pinned against the real thing.  Built by oracle/Makefile
  * into oracle/_ref/libstb_ref.so only when /root/reference exists; never linked into the product.
  */
 #define STB_IMAGE_IMPLEMENTATION

@@ -249,3 +249,42 @@ def test_tier_t3_libm_and_fma_contraction_move_few_channels(box_scene, duck_scen
         assert abs(float(a[0].mean()) - float(b[0].mean())) <= 0.005 * float(a[0].mean())
         assert abs(a[2]["segments"] - b[2]["segments"]) <= 0.002 * a[2]["segments"]
         assert not np.array_equal(a[0], b[0])          # the variant really computes differently
+
+
+def test_jpeg_decoder_is_pinned_to_the_references_stb_image(pt, tmp_path):
+    """Product JPEG decoder (csrc/pt_jpeg.cpp) vs the reference's own third-party/stb_image.h, byte for byte:
+    89 synthetic JPEGs from tests/jpegkit.py -- 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0 / 4:1:1, sequential and
+    progressive (spectral selection + successive approximation with AC refinement and EOB runs), with and
+    without restart intervals, frame sizes from 1x1 up that are not multiples of the MCU, RGB stored as-is,
+    grey (refused: the reference's copy loop would read out of bounds), 16-bit quantisation tables, CMYK,
+    YCCK -- and 11 malformed / unusual files (truncated, 12-bit, arithmetic, lossless, junk, comments).
+    Expected outputs are committed (tests/golden/stb_jpeg_vectors.npz); where oracle/_ref exists the real
+    decoder is run again and must still give the committed bytes."""
+    import pngkit
+    from oracle import ref_stb
+    g = np.load(os.path.join(GOLD, "stb_jpeg_vectors.npz"))
+    names = [str(n) for n in g["names"]]
+    assert len(names) >= 100
+    live = ref_stb.available()
+    p = tmp_path / "t.glb"
+    n_ok = n_refused = 0
+    for name in names:
+        jpg = g["jpg_" + name].tobytes()
+        meta = g["meta_" + name]
+        px = g["px_" + name] if "px_" + name in g else None
+        if live:
+            r = ref_stb.load_from_memory(jpg)
+            assert (r is None) == (meta[0] < 0), name
+            if r is not None:
+                assert list(r[:3]) == list(meta) and np.array_equal(r[3], px), name
+        want = _reference_texels(meta, px)
+        p.write_bytes(pngkit.glb_with_texture(jpg, "image/jpeg"))
+        if want is None:
+            with pytest.raises(RuntimeError):
+                pt.SceneLoader().load(str(p))
+            n_refused += 1
+        else:
+            (tex,) = pt.SceneLoader().load(str(p)).textures
+            assert tex.shape == want.shape and np.array_equal(tex.astype(np.uint8), want), name
+            n_ok += 1
+    assert n_ok >= 85 and n_refused >= 9 and n_ok + n_refused == len(names)
