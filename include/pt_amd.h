@@ -206,7 +206,11 @@ PT_API pt_status pt_kat_closest_hit(pt_device *dev, const float *origins, const 
                                     float *t_out, int *face_out, size_t n);
 
 /* --------------------------------------------------------------- scene I/O (host) -- */
-/* SceneLoader::load(std::string&), HostScene.cpp:98-139, for .glb / .gltf-binary input. */
+/* SceneLoader::load(std::string&), HostScene.cpp:98-139, for glTF 2.0 input: a .glb container or .gltf
+ * JSON text (buffers / images as files next to it, base64 data: URIs or bufferViews).  Node transforms
+ * are baked like aiProcess_PreTransformVertices; textures are PNG or JPEG, decoded to exactly what the
+ * reference's vendored stb_image returns (embedded: native channels + the reference's 3-bytes-per-pixel
+ * copy, HostScene.cpp:19-26,36-46; image files: req_comp = 3, :28-30).                              */
 PT_API pt_status pt_scene_load_glb(const char *path, pt_host_scene **out);
 /* Wavefront OBJ (+ name-prefix material rule of obj_loader.h:65-96 / README.md:60-76). */
 PT_API pt_status pt_scene_load_obj(const char *path, pt_host_scene **out);

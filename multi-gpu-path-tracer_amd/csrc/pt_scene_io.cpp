@@ -362,25 +362,89 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
     std::ifstream f(path, std::ios::binary);
     if (!f) return set_error(PT_ERR_IO, std::string("cannot open ") + path);
     std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    if (file.size() < 20 || memcmp(file.data(), "glTF", 4) != 0)
-        return set_error(PT_ERR_IO, "not a binary glTF (.glb) file");
-    auto le32 = [&](size_t off) { uint32_t v; memcpy(&v, file.data() + off, 4); return v; };
-    if (le32(4) != 2) return set_error(PT_ERR_UNSUPPORTED, "only glTF version 2 is supported");
-    size_t total = std::min<size_t>(le32(8), file.size());
-    size_t pos = 12;
     const uint8_t *json_ptr = nullptr, *bin_ptr = nullptr;
     size_t json_len = 0, bin_len = 0;
-    while (pos + 8 <= total) {
-        uint32_t clen = le32(pos), ctype = le32(pos + 4);
-        if (pos + 8 + (size_t)clen > total) return set_error(PT_ERR_IO, "truncated GLB chunk");
-        if (ctype == 0x4E4F534Au && !json_ptr) { json_ptr = file.data() + pos + 8; json_len = clen; }
-        else if (ctype == 0x004E4942u && !bin_ptr) { bin_ptr = file.data() + pos + 8; bin_len = clen; }
-        pos += 8 + (size_t)clen;
+    size_t first = 0;
+    if (file.size() >= 3 && file[0] == 0xEF && file[1] == 0xBB && file[2] == 0xBF) first = 3;      // UTF-8 BOM
+    while (first < file.size() && (file[first] == ' ' || file[first] == '\n' || file[first] == '\r' || file[first] == '\t')) first++;
+    if (file.size() >= 20 && memcmp(file.data(), "glTF", 4) == 0) {
+        auto le32 = [&](size_t off) { uint32_t v; memcpy(&v, file.data() + off, 4); return v; };
+        if (le32(4) != 2) return set_error(PT_ERR_UNSUPPORTED, "only glTF version 2 is supported");
+        size_t total = std::min<size_t>(le32(8), file.size());
+        size_t pos = 12;
+        while (pos + 8 <= total) {
+            uint32_t clen = le32(pos), ctype = le32(pos + 4);
+            if (pos + 8 + (size_t)clen > total) return set_error(PT_ERR_IO, "truncated GLB chunk");
+            if (ctype == 0x4E4F534Au && !json_ptr) { json_ptr = file.data() + pos + 8; json_len = clen; }
+            else if (ctype == 0x004E4942u && !bin_ptr) { bin_ptr = file.data() + pos + 8; bin_len = clen; }
+            pos += 8 + (size_t)clen;
+        }
+        if (!json_ptr) return set_error(PT_ERR_IO, "GLB has no JSON chunk");
+    } else if (first < file.size() && file[first] == '{') {
+        json_ptr = file.data() + first; json_len = file.size() - first;       // .gltf: JSON text, buffers and images by uri
+    } else {
+        return set_error(PT_ERR_IO, "not a glTF file (neither a .glb container nor .gltf JSON)");
     }
-    if (!json_ptr) return set_error(PT_ERR_IO, "GLB has no JSON chunk");
     JsonParser jp{(const char *)json_ptr, (const char *)json_ptr + json_len};
     Json root = jp.value();
-    if (!jp.ok || root.kind != Json::Obj) return set_error(PT_ERR_IO, "GLB JSON chunk does not parse");
+    if (!jp.ok || root.kind != Json::Obj) return set_error(PT_ERR_IO, "glTF JSON does not parse");
+
+    // ---- buffers: the GLB BIN chunk (buffer 0 without a uri), data: URIs, files next to the .gltf
+    std::string dir(path);
+    {
+        size_t slash = dir.find_last_of("/\\");
+        dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    }
+    auto load_uri = [&](const std::string &uri, std::vector<uint8_t> &out_bytes, bool &was_data_uri) -> pt_status {
+        was_data_uri = uri.compare(0, 5, "data:") == 0;
+        if (was_data_uri) {
+            size_t comma = uri.find(',');
+            if (comma == std::string::npos || uri.find(";base64") == std::string::npos || uri.find(";base64") > comma)
+                return set_error(PT_ERR_UNSUPPORTED, "only base64 data: URIs are supported");
+            out_bytes.clear();
+            uint32_t acc = 0; int nb = 0;
+            for (size_t i = comma + 1; i < uri.size(); i++) {
+                const char ch = uri[i];
+                int v;
+                if (ch >= 'A' && ch <= 'Z') v = ch - 'A';
+                else if (ch >= 'a' && ch <= 'z') v = ch - 'a' + 26;
+                else if (ch >= '0' && ch <= '9') v = ch - '0' + 52;
+                else if (ch == '+' || ch == '-') v = 62;
+                else if (ch == '/' || ch == '_') v = 63;
+                else continue;                                   // padding, line breaks
+                acc = (acc << 6) | (uint32_t)v; nb += 6;
+                if (nb >= 8) { nb -= 8; out_bytes.push_back((uint8_t)((acc >> nb) & 0xff)); }
+            }
+            return PT_OK;
+        }
+        std::string rel;
+        for (size_t i = 0; i < uri.size(); i++) {                // percent-decoding
+            if (uri[i] == '%' && i + 2 < uri.size() && isxdigit((unsigned char)uri[i + 1]) && isxdigit((unsigned char)uri[i + 2])) {
+                rel.push_back((char)strtol(uri.substr(i + 1, 2).c_str(), nullptr, 16));
+                i += 2;
+            } else rel.push_back(uri[i]);
+        }
+        const std::string full = (!rel.empty() && rel[0] == '/') ? rel : dir + "/" + rel;
+        std::ifstream bf(full, std::ios::binary);
+        if (!bf) return set_error(PT_ERR_IO, "cannot open " + full);
+        out_bytes.assign((std::istreambuf_iterator<char>(bf)), std::istreambuf_iterator<char>());
+        return PT_OK;
+    };
+    const Json *jbuf = root.get("buffers");
+    std::vector<std::vector<uint8_t>> ext_buffers(jbuf ? jbuf->size() : 0);
+    std::vector<std::pair<const uint8_t *, size_t>> buffers(jbuf ? jbuf->size() : 0, std::make_pair((const uint8_t *)nullptr, (size_t)0));
+    for (size_t i = 0; jbuf && i < jbuf->size(); i++) {
+        const Json *uri = jbuf->at(i).get("uri");
+        if (!uri) {
+            if (i == 0 && bin_ptr) buffers[i] = std::make_pair(bin_ptr, bin_len);
+            continue;
+        }
+        bool is_data = false;
+        pt_status st = load_uri(uri->str, ext_buffers[i], is_data);
+        if (st != PT_OK) return st;
+        buffers[i] = std::make_pair(ext_buffers[i].data(), ext_buffers[i].size());
+    }
+    if (buffers.empty() && bin_ptr) buffers.push_back(std::make_pair(bin_ptr, bin_len));
 
     const Json *jviews = root.get("bufferViews");
     const Json *jacc = root.get("accessors");
@@ -388,12 +452,12 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
         if (!jviews || view < 0 || (size_t)view >= jviews->size()) return false;
         const Json &v = jviews->at((size_t)view);
         int buffer = v.get("buffer") ? v.get("buffer")->integer(0) : 0;
-        if (buffer != 0 || !bin_ptr) return false;          // GLB-embedded buffer only
+        if (buffer < 0 || (size_t)buffer >= buffers.size() || !buffers[(size_t)buffer].first) return false;
         size_t off = v.get("byteOffset") ? (size_t)v.get("byteOffset")->number(0) : 0;
         len = v.get("byteLength") ? (size_t)v.get("byteLength")->number(0) : 0;
         stride = v.get("byteStride") ? (size_t)v.get("byteStride")->number(0) : 0;
-        if (off + len > bin_len) return false;
-        ptr = bin_ptr + off;
+        if (off + len > buffers[(size_t)buffer].second) return false;
+        ptr = buffers[(size_t)buffer].first + off;
         return true;
     };
     auto get_accessor = [&](int idx, Accessor &a) -> bool {
@@ -456,15 +520,37 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
         if (it != image_to_tex.end()) { out_idx = it->second; return PT_OK; }
         const Json &ji = jimg->at((size_t)img);
         const Json *bv = ji.get("bufferView");
-        if (!bv) return set_error(PT_ERR_UNSUPPORTED, "external (uri) images are not supported; embed them in the GLB");
-        const uint8_t *ptr; size_t len, stride;
-        if (!view_span(bv->integer(-1), ptr, len, stride)) return set_error(PT_ERR_IO, "bad image bufferView");
+        const uint8_t *ptr = nullptr; size_t len = 0, stride = 0;
+        std::vector<uint8_t> image_file;
+        // Images in a bufferView or a data: URI reach the reference as assimp "embedded textures" ->
+        // stbi_load_from_memory(req_comp = 0) + the 3-bytes-per-pixel copy loop (HostScene.cpp:18-26,36-46).
+        // Images in a file next to the .gltf take the other branch, stbi_load(path, req_comp = 3) (:28-30):
+        // stb_image converts them to RGB itself (grey replicated, alpha dropped).
+        bool external_file = false;
+        if (bv) {
+            if (!view_span(bv->integer(-1), ptr, len, stride)) return set_error(PT_ERR_IO, "bad image bufferView");
+        } else if (ji.get("uri")) {
+            bool is_data = false;
+            pt_status st = load_uri(ji.get("uri")->str, image_file, is_data);
+            if (st != PT_OK) return st;
+            ptr = image_file.data(); len = image_file.size();
+            external_file = !is_data;
+        } else {
+            return set_error(PT_ERR_IO, "image without bufferView or uri");
+        }
         int w = 0, h = 0, ch = 0;
         std::vector<uint8_t> px;
         // stb_image tries PNG first and JPEG later (stb_image.h stbi__load_main); GLB images are one of the two
         const bool is_jpeg = len >= 3 && ptr[0] == 0xff && ptr[1] == 0xd8 && ptr[2] == 0xff;
         pt_status st = is_jpeg ? decode_jpeg(ptr, len, w, h, ch, px) : decode_png(ptr, len, w, h, ch, px);
         if (st != PT_OK) return st;
+        if (external_file && ch != 3) {                          // stbi__convert_format to 3 channels
+            std::vector<uint8_t> rgb((size_t)w * (size_t)h * 3);
+            for (size_t i = 0; i < (size_t)w * (size_t)h; i++)
+                for (int c = 0; c < 3; c++) rgb[3 * i + c] = px[i * (size_t)ch + (ch >= 3 ? (size_t)c : 0)];
+            px.swap(rgb);
+            ch = 3;
+        }
         // HostScene.cpp:36-46: the copy loop assumes 3 bytes per pixel whatever the file has.
         if (ch < 3) return set_error(PT_ERR_UNSUPPORTED, "textures with fewer than 3 channels are read out of bounds by the reference (HostScene.cpp:38-46)");
         std::vector<float> texels((size_t)w * (size_t)h * 3);

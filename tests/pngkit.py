@@ -181,3 +181,34 @@ def png_malformed(seed=12):
     out["not_a_png"] = b"\xff\xd8\xff\xe0" + bytes(64)
     out["bit_depth_3"] = good[:24] + b"\x03" + good[25:]
     return out
+
+
+def glb_to_gltf(glb_path, out_dir, images="file", buffer="file"):
+    """Rewrites a .glb as .gltf JSON text: the BIN chunk becomes scene.bin (or a base64 data: URI), every image
+    a file next to it (images="file"), a data: URI ("data"), or stays a bufferView ("view")."""
+    import base64
+    import os
+    blob = open(glb_path, "rb").read()
+    jlen = struct.unpack_from("<I", blob, 12)[0]
+    j = json.loads(blob[20:20 + jlen])
+    blen = struct.unpack_from("<I", blob, 20 + jlen)[0]
+    bin0 = blob[20 + jlen + 8:20 + jlen + 8 + blen]
+    if buffer == "file":
+        open(os.path.join(out_dir, "scene data.bin"), "wb").write(bin0)
+        j["buffers"][0]["uri"] = "scene%20data.bin"                      # percent-encoded space
+    else:
+        j["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(bin0).decode()
+    for k, im in enumerate(j.get("images", [])):
+        if images == "view":
+            continue
+        bv = j["bufferViews"][im.pop("bufferView")]
+        data = bin0[bv.get("byteOffset", 0):bv.get("byteOffset", 0) + bv["byteLength"]]
+        ext = "png" if data[:4] == b"\x89PNG" else "jpg"
+        if images == "file":
+            open(os.path.join(out_dir, "img%d.%s" % (k, ext)), "wb").write(data)
+            im["uri"] = "img%d.%s" % (k, ext)
+        else:
+            im["uri"] = "data:image/%s;base64,%s" % ("png" if ext == "png" else "jpeg", base64.b64encode(data).decode())
+    path = os.path.join(out_dir, "scene.gltf")
+    open(path, "w").write("﻿" + json.dumps(j, indent=1))          # with a BOM, as some exporters write
+    return path

@@ -410,6 +410,26 @@ def test_embedded_png_variants(pt, tmp_path):
         pt.SceneLoader().load(str(p))
 
 
+@pytest.mark.parametrize("images,buffer", [("file", "file"), ("data", "data"), ("view", "file")])
+def test_gltf_text_container_equals_glb(pt, duck_scene, box_scene, tmp_path, images, buffer):
+    """.gltf (JSON text, UTF-8 BOM) with the buffer as a percent-encoded file name or a base64 data: URI and the
+    images as files, data: URIs or bufferViews loads to the same HostScene as the .glb it was made from."""
+    import pngkit
+    for model, ref in (("cornell_duck.glb", duck_scene), ("cornell_box.glb", None)):
+        d = tmp_path / model.replace(".", "_")
+        d.mkdir()
+        path = pngkit.glb_to_gltf(os.path.join(ROOT, "models", model), str(d), images=images, buffer=buffer)
+        sc = pt.SceneLoader().load(path)
+        want = ref if ref is not None else pt.SceneLoader().load(os.path.join(ROOT, "models", model))
+        assert np.array_equal(sc.triangles, want.triangles) and np.array_equal(sc.materials, want.materials)
+        assert len(sc.textures) == len(want.textures)
+        for a, b in zip(sc.textures, want.textures):
+            assert np.array_equal(a, b)
+    with pytest.raises(RuntimeError):
+        (tmp_path / "bad.gltf").write_text('{"asset": {"version": "2.0"}, "buffers": [{"uri": "missing.bin", "byteLength": 4}]}')
+        pt.SceneLoader().load(str(tmp_path / "bad.gltf"))
+
+
 def test_sah_tree_invariants_and_determinism(pt, duck_scene):
     """Opt-in SAH tree (host build, threaded for big inputs): every triangle sits in exactly one leaf
     of <= 4, every child box (inflated) contains its triangles, child links form a tree in which

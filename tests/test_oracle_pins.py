@@ -288,3 +288,51 @@ def test_jpeg_decoder_is_pinned_to_the_references_stb_image(pt, tmp_path):
             assert tex.shape == want.shape and np.array_equal(tex.astype(np.uint8), want), name
             n_ok += 1
     assert n_ok >= 85 and n_refused >= 9 and n_ok + n_refused == len(names)
+
+
+def test_external_image_files_follow_stb_image_req_comp_3(pt, tmp_path):
+    """Images stored as files next to a .gltf reach the reference through stbi_load(path, req_comp = 3)
+    (HostScene.cpp:28-30), not through the embedded-texture branch: stb_image itself converts to RGB (grey
+    replicated, alpha dropped), so nothing is mis-strided or out of bounds there.  The product decodes
+    natively and applies that conversion; checked for every PNG / JPEG vector against the native-channel
+    golden data and, where oracle/_ref exists, against the real stbi call with req_comp = 3."""
+    import json
+    import struct
+    import pngkit
+    from oracle import ref_stb
+    live = ref_stb.available()
+    pos = struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + struct.pack("<6f", 0, 0, 1, 0, 0, 1)
+    (tmp_path / "geo.bin").write_bytes(pos)
+    checked = 0
+    for fixture, prefix, ext in (("stb_png_vectors.npz", "png_", "png"), ("stb_jpeg_vectors.npz", "jpg_", "jpg")):
+        g = np.load(os.path.join(GOLD, fixture))
+        for name in (str(n) for n in g["names"]):
+            data = g[prefix + name].tobytes()
+            meta = g["meta_" + name]
+            (tmp_path / ("tex." + ext)).write_bytes(data)
+            gltf = {
+                "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+                "buffers": [{"byteLength": len(pos), "uri": "geo.bin"}],
+                "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 24}],
+                "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"},
+                              {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC2"}],
+                "images": [{"uri": "tex." + ext}], "textures": [{"source": 0}],
+                "materials": [{"emissiveFactor": [1, 1, 1], "pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}],
+                "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1}, "material": 0}]}],
+            }
+            p = tmp_path / "scene.gltf"
+            p.write_text(json.dumps(gltf))
+            if meta[0] < 0:
+                with pytest.raises(RuntimeError):
+                    pt.SceneLoader().load(str(p))
+                continue
+            w, h, comp = (int(v) for v in meta)
+            px = g["px_" + name].reshape(h, w, comp)
+            want = px[..., :3] if comp >= 3 else np.repeat(px[..., :1], 3, axis=2)
+            if live:
+                r = ref_stb.load_from_memory(data, 3)
+                assert r is not None and np.array_equal(r[3].reshape(h, w, 3), want), name
+            (tex,) = pt.SceneLoader().load(str(p)).textures
+            assert tex.shape == (h, w, 3) and np.array_equal(tex.astype(np.uint8), want), name
+            checked += 1
+    assert checked >= 120
