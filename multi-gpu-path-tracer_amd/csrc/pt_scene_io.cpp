@@ -650,10 +650,8 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
         for (size_t pi = 0; pi < prims->size(); pi++) {
             const Json &pr = prims->at(pi);
             int mode = pr.get("mode") ? pr.get("mode")->integer(4) : 4;
-            if (mode != 4) {
-                if (mode <= 3) continue;      // points / lines: removed by SortByPType (HostScene.cpp:99)
-                return set_error(PT_ERR_UNSUPPORTED, "triangle strips / fans are not supported");
-            }
+            if (mode <= 3) continue;          // points / lines: removed by SortByPType (HostScene.cpp:99)
+            if (mode > 6) return set_error(PT_ERR_IO, "bad primitive mode");
             const Json *attrs = pr.get("attributes");
             if (!attrs || !attrs->get("POSITION")) continue;
             Accessor apos, auv, aidx;
@@ -679,10 +677,19 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
                 }
             }
             size_t nidx = has_idx ? aidx.count : apos.count;
-            for (size_t t = 0; t + 2 < nidx; t += 3) {
-                uint32_t i0 = has_idx ? read_index(aidx, t) : (uint32_t)t;
-                uint32_t i1 = has_idx ? read_index(aidx, t + 1) : (uint32_t)(t + 1);
-                uint32_t i2 = has_idx ? read_index(aidx, t + 2) : (uint32_t)(t + 2);
+            auto index_at = [&](size_t k) -> uint32_t { return has_idx ? read_index(aidx, k) : (uint32_t)k; };
+            // TRIANGLES (4): consecutive triples.  TRIANGLE_STRIP (5) / TRIANGLE_FAN (6) are unrolled the way
+            // assimp's glTF2 importer does (recalled from assimp 5.4, not verifiable here):
+            // strip triangle n = (n, n+1, n+2), odd n as (n+1, n, n+2) to keep the orientation; fan triangle
+            // n = (first, last vertex of triangle n-1, n+2).
+            const size_t nfaces = mode == 4 ? nidx / 3 : (nidx >= 3 ? nidx - 2 : 0);
+            for (size_t t = 0; t < nfaces; t++) {
+                uint32_t i0, i1, i2;
+                if (mode == 4) { i0 = index_at(3 * t); i1 = index_at(3 * t + 1); i2 = index_at(3 * t + 2); }
+                else if (mode == 5) {
+                    if (t & 1) { i0 = index_at(t + 1); i1 = index_at(t); i2 = index_at(t + 2); }
+                    else { i0 = index_at(t); i1 = index_at(t + 1); i2 = index_at(t + 2); }
+                } else { i0 = index_at(0); i1 = index_at(t + 1); i2 = index_at(t + 2); }
                 if (i0 >= apos.count || i1 >= apos.count || i2 >= apos.count) return set_error(PT_ERR_IO, "vertex index out of range");
                 if (flip) std::swap(i0, i2);
                 pt_triangle tri;

@@ -257,6 +257,23 @@ def test_glb_loader_handcrafted_files(pt, tmp_path):
     p.write_bytes(_minimal_glb(dict(base, nodes=[{"mesh": 0}]), deg))
     with pytest.raises(RuntimeError):
         pt.SceneLoader().load(str(p))
+    # triangle strip / fan of 5 vertices: 3 triangles each, strip triangle 1 re-ordered to keep the orientation
+    five = struct.pack("<15f", 0, 0, 0, 1, 0, 0, 0, 1, 0, 1, 1, 0, 0, 2, 0)
+    v = [[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0, 2, 0]]
+    sf = dict(base, nodes=[{"mesh": 0}], buffers=[{"byteLength": len(five)}],
+              bufferViews=[{"buffer": 0, "byteOffset": 0, "byteLength": len(five)}],
+              accessors=[{"bufferView": 0, "componentType": 5126, "count": 5, "type": "VEC3"}])
+    for mode, want in ((5, [(0, 1, 2), (2, 1, 3), (2, 3, 4)]), (6, [(0, 1, 2), (0, 2, 3), (0, 3, 4)])):
+        sf["meshes"] = [{"primitives": [{"attributes": {"POSITION": 0}, "mode": mode}]}]
+        p.write_bytes(_minimal_glb(sf, five))
+        tr = pt.SceneLoader().load(str(p)).triangles
+        got = [tuple(v.index(t[k]["position"].tolist()) for k in ("v0", "v1", "v2")) for t in tr]
+        assert got == want, (mode, got)
+    # points and lines are dropped (SortByPType), leaving nothing to render
+    sf["meshes"] = [{"primitives": [{"attributes": {"POSITION": 0}, "mode": 1}]}]
+    p.write_bytes(_minimal_glb(sf, five))
+    with pytest.raises(RuntimeError):
+        pt.SceneLoader().load(str(p))
     # malformed: accessor beyond the buffer, index out of range, truncated chunk, garbage JSON
     bad = dict(base, nodes=[{"mesh": 0}]); bad["accessors"] = [{"bufferView": 0, "componentType": 5126, "count": 300, "type": "VEC3"}]
     p.write_bytes(_minimal_glb(bad, pos))
