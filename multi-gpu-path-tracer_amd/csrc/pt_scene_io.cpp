@@ -333,6 +333,7 @@ struct Accessor {
     size_t count = 0, stride = 0;
     int componentType = 0, ncomp = 0;
     bool normalized = false;
+    std::shared_ptr<std::vector<uint8_t>> owned;     // sparse accessors are materialised here
 };
 
 size_t comp_size(int ct)
@@ -463,21 +464,48 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
     auto get_accessor = [&](int idx, Accessor &a) -> bool {
         if (!jacc || idx < 0 || (size_t)idx >= jacc->size()) return false;
         const Json &j = jacc->at((size_t)idx);
-        if (j.get("sparse")) return false;
-        const Json *bv = j.get("bufferView");
-        if (!bv) return false;
-        const uint8_t *ptr; size_t len, stride;
-        if (!view_span(bv->integer(-1), ptr, len, stride)) return false;
-        size_t off = j.get("byteOffset") ? (size_t)j.get("byteOffset")->number(0) : 0;
         a.componentType = j.get("componentType") ? j.get("componentType")->integer(0) : 0;
         a.ncomp = j.get("type") ? type_ncomp(j.get("type")->str) : 0;
         a.count = j.get("count") ? (size_t)j.get("count")->number(0) : 0;
         a.normalized = j.get("normalized") && j.get("normalized")->b;
-        size_t cs = comp_size(a.componentType);
+        const size_t cs = comp_size(a.componentType);
         if (!cs || !a.ncomp) return false;
-        a.stride = stride ? stride : cs * (size_t)a.ncomp;
-        if (a.count && off + (a.count - 1) * a.stride + cs * (size_t)a.ncomp > len) return false;
-        a.base = ptr + off;
+        const size_t elem = cs * (size_t)a.ncomp;
+        const Json *bv = j.get("bufferView");
+        const Json *sparse = j.get("sparse");
+        if (!bv && !sparse) return false;
+        if (bv) {
+            const uint8_t *ptr; size_t len, stride;
+            if (!view_span(bv->integer(-1), ptr, len, stride)) return false;
+            size_t off = j.get("byteOffset") ? (size_t)j.get("byteOffset")->number(0) : 0;
+            a.stride = stride ? stride : elem;
+            if (a.count && off + (a.count - 1) * a.stride + elem > len) return false;
+            a.base = ptr + off;
+        }
+        if (!sparse) return true;
+        // sparse accessor (glTF 2.0 section 3.6.2.3): the base view, or zeros, with `count` elements replaced
+        if (a.count > ((size_t)1 << 28)) return false;
+        auto dense = std::make_shared<std::vector<uint8_t>>(a.count * elem, (uint8_t)0);
+        if (bv) for (size_t i = 0; i < a.count; i++) memcpy(dense->data() + i * elem, a.base + i * a.stride, elem);
+        const Json *si = sparse->get("indices"), *sv = sparse->get("values");
+        const size_t n = sparse->get("count") ? (size_t)sparse->get("count")->number(0) : 0;
+        if (!si || !sv || !si->get("bufferView") || !sv->get("bufferView")) return false;
+        const uint8_t *ip, *vp; size_t il, vl, st;
+        if (!view_span(si->get("bufferView")->integer(-1), ip, il, st) || !view_span(sv->get("bufferView")->integer(-1), vp, vl, st)) return false;
+        const size_t ioff = si->get("byteOffset") ? (size_t)si->get("byteOffset")->number(0) : 0;
+        const size_t voff = sv->get("byteOffset") ? (size_t)sv->get("byteOffset")->number(0) : 0;
+        const int ict = si->get("componentType") ? si->get("componentType")->integer(0) : 0;
+        const size_t ics = comp_size(ict);
+        if (!(ict == 5121 || ict == 5123 || ict == 5125) || ioff + n * ics > il || voff + n * elem > vl) return false;
+        for (size_t k = 0; k < n; k++) {
+            uint32_t at = 0;
+            memcpy(&at, ip + ioff + k * ics, ics);               // little-endian host
+            if (at >= a.count) return false;
+            memcpy(dense->data() + (size_t)at * elem, vp + voff + k * elem, elem);
+        }
+        a.owned = dense;
+        a.base = dense->data();
+        a.stride = elem;
         return true;
     };
     auto read_float = [&](const Accessor &a, size_t i, int c) -> float {

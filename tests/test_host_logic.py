@@ -269,6 +269,31 @@ def test_glb_loader_handcrafted_files(pt, tmp_path):
         tr = pt.SceneLoader().load(str(p)).triangles
         got = [tuple(v.index(t[k]["position"].tolist()) for k in ("v0", "v1", "v2")) for t in tr]
         assert got == want, (mode, got)
+    # sparse accessor: zero-initialised positions (no bufferView) with two vertices supplied, and a base view
+    # with one vertex replaced
+    spi = struct.pack("<2H", 1, 2)
+    spv = struct.pack("<6f", 3, 0, 0, 0, 4, 0)
+    blob = pos + spi + spv
+    sp = dict(base, nodes=[{"mesh": 0}], buffers=[{"byteLength": len(blob)}],
+              bufferViews=[{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 4},
+                           {"buffer": 0, "byteOffset": 40, "byteLength": 24}])
+    sparse = {"count": 2, "indices": {"bufferView": 1, "componentType": 5123}, "values": {"bufferView": 2}}
+    sp["accessors"] = [{"componentType": 5126, "count": 3, "type": "VEC3", "sparse": sparse}]
+    p.write_bytes(_minimal_glb(sp, blob))
+    t = pt.SceneLoader().load(str(p)).triangles[0]
+    assert [t[k]["position"].tolist() for k in ("v0", "v1", "v2")] == [[0, 0, 0], [3, 0, 0], [0, 4, 0]]
+    sp["accessors"] = [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3",
+                        "sparse": {"count": 1, "indices": {"bufferView": 1, "componentType": 5123}, "values": {"bufferView": 2}}}]
+    p.write_bytes(_minimal_glb(sp, blob))
+    t = pt.SceneLoader().load(str(p)).triangles[0]
+    assert [t[k]["position"].tolist() for k in ("v0", "v1", "v2")] == [[0, 0, 0], [3, 0, 0], [0, 1, 0]]
+    sp["accessors"][0]["sparse"]["indices"]["byteOffset"] = 2                    # index 2, then the first value
+    p.write_bytes(_minimal_glb(sp, blob))
+    assert pt.SceneLoader().load(str(p)).triangles[0]["v2"]["position"].tolist() == [3, 0, 0]
+    sp["accessors"][0]["sparse"]["count"] = 9                                    # beyond the index view
+    p.write_bytes(_minimal_glb(sp, blob))
+    with pytest.raises(RuntimeError):
+        pt.SceneLoader().load(str(p))
     # points and lines are dropped (SortByPType), leaving nothing to render
     sf["meshes"] = [{"primitives": [{"attributes": {"POSITION": 0}, "mode": 1}]}]
     p.write_bytes(_minimal_glb(sf, five))
