@@ -161,8 +161,11 @@ inline uint8_t clamp255(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x
 // 2 extra bits kept between the passes, +128 level shift folded into the final rounding.
 inline int fx(double x) { return (int)(x * 4096 + 0.5); }
 
+// Intermediates are 64-bit and are cut back to 32 bits only where the reference shifts: same bits as its
+// 32-bit arithmetic on any real image, and no signed overflow (undefined behaviour) on corrupt ones,
+// where dequantised coefficients can be anything.
 #define PT_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                       \
-    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                               \
+    long long t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                         \
     p2 = s2; p3 = s6;                                                                                     \
     p1 = (p2 + p3) * fx(0.5411961f);                                                                      \
     t2 = p1 + p3 * fx(-1.847759065f);                                                                     \
@@ -187,22 +190,35 @@ void idct_block(uint8_t *out, int stride, const int16_t in[64])
         int *v = val + i;
         PT_IDCT_1D(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56])
         x0 += 512; x1 += 512; x2 += 512; x3 += 512;
-        v[0] = (x0 + t3) >> 10;  v[56] = (x0 - t3) >> 10;
-        v[8] = (x1 + t2) >> 10;  v[48] = (x1 - t2) >> 10;
-        v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10;
-        v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+        v[0] = (int32_t)(x0 + t3) >> 10;  v[56] = (int32_t)(x0 - t3) >> 10;
+        v[8] = (int32_t)(x1 + t2) >> 10;  v[48] = (int32_t)(x1 - t2) >> 10;
+        v[16] = (int32_t)(x2 + t1) >> 10; v[40] = (int32_t)(x2 - t1) >> 10;
+        v[24] = (int32_t)(x3 + t0) >> 10; v[32] = (int32_t)(x3 - t0) >> 10;
     }
     for (int i = 0; i < 8; i++) {
         const int *v = val + 8 * i;
         uint8_t *o = out + (size_t)i * (size_t)stride;
         PT_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
-        const int bias = 65536 + (128 << 17);
+        const long long bias = 65536 + (128 << 17);
         x0 += bias; x1 += bias; x2 += bias; x3 += bias;
-        o[0] = clamp255((x0 + t3) >> 17); o[7] = clamp255((x0 - t3) >> 17);
-        o[1] = clamp255((x1 + t2) >> 17); o[6] = clamp255((x1 - t2) >> 17);
-        o[2] = clamp255((x2 + t1) >> 17); o[5] = clamp255((x2 - t1) >> 17);
-        o[3] = clamp255((x3 + t0) >> 17); o[4] = clamp255((x3 - t0) >> 17);
+        o[0] = clamp255((int32_t)(x0 + t3) >> 17); o[7] = clamp255((int32_t)(x0 - t3) >> 17);
+        o[1] = clamp255((int32_t)(x1 + t2) >> 17); o[6] = clamp255((int32_t)(x1 - t2) >> 17);
+        o[2] = clamp255((int32_t)(x2 + t1) >> 17); o[5] = clamp255((int32_t)(x2 - t1) >> 17);
+        o[3] = clamp255((int32_t)(x3 + t0) >> 17); o[4] = clamp255((int32_t)(x3 - t0) >> 17);
     }
+}
+
+// DC bookkeeping with the reference's validity checks (stb_image.h "bad delta", "can't merge dc and ac"):
+// the running predictor must not overflow and the scaled DC must fit the 16-bit coefficient.
+bool next_dc(Component &c, int diff, int scale, int16_t &out)
+{
+    const long long dc = (long long)c.dc_pred + diff;
+    if (dc > 2147483647ll || dc < -2147483647ll - 1) return fail("JPEG: DC predictor overflow");
+    c.dc_pred = (int)dc;
+    const long long v = dc * scale;
+    if (v > 32767 || v < -32768) return fail("JPEG: DC coefficient out of range");
+    out = (int16_t)v;
+    return true;
 }
 
 // One block of a sequential scan (T.81 F.2.2): DC difference, AC run/size pairs; dequantised on the fly.
@@ -213,8 +229,7 @@ bool decode_block_sequential(Decoder &d, int16_t blk[64], Component &c)
     const int t = huff_decode(d, hdc);
     if (t < 0 || t > 15) return fail("JPEG: bad Huffman code");
     memset(blk, 0, 64 * sizeof(int16_t));
-    c.dc_pred += t ? extend_receive(d, t) : 0;
-    blk[0] = (int16_t)(c.dc_pred * dq[0]);
+    if (!next_dc(c, t ? extend_receive(d, t) : 0, dq[0], blk[0])) return false;
     int k = 1;
     do {
         const int rs = huff_decode(d, hac);
@@ -241,8 +256,7 @@ bool decode_block_prog_dc(Decoder &d, int16_t blk[64], Component &c)
         memset(blk, 0, 64 * sizeof(int16_t));
         const int t = huff_decode(d, d.dc[c.td]);
         if (t < 0 || t > 15) return fail("JPEG: bad Huffman code");
-        c.dc_pred += t ? extend_receive(d, t) : 0;
-        blk[0] = (int16_t)(c.dc_pred * (1 << d.al));
+        if (!next_dc(c, t ? extend_receive(d, t) : 0, 1 << d.al, blk[0])) return false;
     } else if (get_bit(d)) {
         blk[0] = (int16_t)(blk[0] + (1 << d.al));
     }
@@ -478,7 +492,8 @@ bool frame_header(Decoder &d)
         k.tq = get8(d);
         if (k.tq > 3) return fail("JPEG: bad quantisation table index");
     }
-    if ((uint64_t)d.W * (uint64_t)d.H * (uint64_t)c > ((uint64_t)1 << 31)) return fail("JPEG: image too large");
+    // (stb_image refuses beyond 2^31 bytes of output; more than 2^28 pixels is a corrupt header, not a texture)
+    if ((uint64_t)d.W * (uint64_t)d.H > ((uint64_t)1 << 28)) return fail("JPEG: image too large");
     d.hmax = d.vmax = 1;
     for (int i = 0; i < c; i++) { d.hmax = std::max(d.hmax, d.comp[i].h); d.vmax = std::max(d.vmax, d.comp[i].v); }
     for (int i = 0; i < c; i++)

@@ -212,6 +212,10 @@ pt_status decode_png(const uint8_t *data, size_t len, int &w, int &h, int &chann
         pos += 12 + (size_t)clen;
     }
     if (!have_ihdr || w <= 0 || h <= 0) return set_error(PT_ERR_IO, "PNG without IHDR");
+    // stb_image.h: STBI_MAX_DIMENSIONS (1 << 24) per side and "too large" beyond 2^30 bytes; a texture of
+    // more than 2^28 pixels is a corrupt header, not a texture
+    if (w > (1 << 24) || h > (1 << 24) || (uint64_t)w * (uint64_t)h > ((uint64_t)1 << 28))
+        return set_error(PT_ERR_IO, "PNG too large");
     if (interlace > 1) return set_error(PT_ERR_IO, "bad PNG interlace method");
     int spp;   // samples per pixel in the file
     switch (ctype) {
@@ -242,6 +246,8 @@ pt_status decode_png(const uint8_t *data, size_t len, int &w, int &h, int &chann
         const int pw = (w - pass[k][0] + pass[k][2] - 1) / pass[k][2], ph = (h - pass[k][1] + pass[k][3] - 1) / pass[k][3];
         if (pw > 0 && ph > 0) raw_need += (((size_t)pw * bits_pp + 7) / 8 + 1) * (size_t)ph;
     }
+    // deflate cannot expand by more than ~1032:1: do not allocate what the data cannot fill
+    if (raw_need > idat.size() * 1040 + 1024) return set_error(PT_ERR_IO, "PNG inflate failed");
     std::vector<uint8_t> raw(raw_need);
     uLongf rawlen = (uLongf)raw.size();
     int zr = uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size());
