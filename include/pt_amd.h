@@ -105,6 +105,23 @@ PT_API pt_status pt_set_thread_block_size(pt_device *dev, unsigned x, unsigned y
  * distance pruning: same Moller-Trumbore arithmetic and tie-breaking, but a
  * different set of tested triangles, so ill-conditioned rays can resolve differently.     */
 PT_API pt_status pt_set_bvh_mode(pt_device *dev, int mode);
+/* EXTENSION, off by default: the reference's legacy material classes and its sphere.
+ * kind 0 = UniversalMaterial (the live path; albedo / param ignored), 1 = lambertian(albedo)
+ * material.h:110-127, 2 = metal(albedo, fuzz = param) :130-144, 3 = dielectric(ir = param) :146-178,
+ * 4 = diffuse_light(color = albedo) :210-217.  pt_sphere = sphere(center, radius, material) sphere.h:8-50;
+ * spheres are tested after the BVH like members of a hitable_list.  No integrator of the reference at
+ * HEAD calls these classes: the loop that drives them here is the classic one their scatter()/emitted()
+ * signatures were written for (end on emitters and absorbed rays, else throughput *= attenuation and
+ * follow the scattered ray); pow(x,5) in the Schlick term is ((x*x)*(x*x))*x.  PARITY UNPINNED; kernel and
+ * oracle agree bit for bit.  The records apply to the NEXT pt_upload_scene (one per material; pass 0
+ * materials and 0 spheres to switch the extension off); they need the reference tree (bvh mode 0).
+ * Only faces with an emissive UniversalMaterial are light-sampled (DevicePathTracer.h:304-307), and a
+ * scene without such a face is accepted only when nothing in it uses kind 0.                       */
+typedef struct pt_legacy_material { int kind; float albedo[3]; float param; } pt_legacy_material;
+typedef struct pt_sphere { float center[3]; float radius; int materialIdx; } pt_sphere;
+PT_API pt_status pt_set_legacy_scene(pt_device *dev, const pt_legacy_material *materials, size_t n_materials,
+                                     const pt_sphere *spheres, size_t n_spheres);
+
 /* Order in which a launch hands its 8x8-pixel tiles to waves.  0: raster order.  1 (default):
  * cost order -- every launch records what each tile cost (shader-clock ticks) and a device radix
  * sort makes that the next launch's order for the same task rectangle / band set, dearest tiles

@@ -24,6 +24,10 @@ TRIANGLE_DTYPE = np.dtype([("v0", VERTEX_DTYPE), ("v1", VERTEX_DTYPE), ("v2", VE
 MATERIAL_DTYPE = np.dtype([("baseColor", np.float32, 3), ("baseColorTextureIdx", np.int32),
                            ("emissiveFactor", np.float32, 3), ("emissiveTextureIdx", np.int32)])
 assert TRIANGLE_DTYPE.itemsize == 68 and MATERIAL_DTYPE.itemsize == 32
+# extension records (pt_set_legacy_scene)
+LEGACY_MATERIAL_DTYPE = np.dtype([("kind", np.int32), ("albedo", np.float32, 3), ("param", np.float32)])
+SPHERE_DTYPE = np.dtype([("center", np.float32, 3), ("radius", np.float32), ("materialIdx", np.int32)])
+assert LEGACY_MATERIAL_DTYPE.itemsize == 20 and SPHERE_DTYPE.itemsize == 20
 
 
 class Texture(C.Structure):
@@ -93,6 +97,7 @@ _PROTOS = {
     "pt_fb_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "pt_fb_download_task": (C.c_int, [_vp, C.POINTER(Task), _vp, _vp, _vp]),
     "pt_set_tile_schedule": (C.c_int, [_vp, C.c_int]),
+    "pt_set_legacy_scene": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
     "pt_kat_arith": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t]),
     "pt_kat_exhaustive": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint64, _vp, _vp, C.c_int]),
     "pt_kat_closest_hit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_size_t]),

@@ -39,7 +39,7 @@ namespace dev {
 // nodes), 2 = wave-uniform walk with the per-lane LDS stack (medium trees), 3 = SAH tree walk.
 // render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
 // camera::ray_color (camera.h:49-83) flattened into a per-lane state machine.
-template <bool kLds, bool kPacked, int kWalk>
+template <bool kLds, bool kPacked, int kWalk, bool kLegacy = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDER_WAVES, PT_RENDER_WAVES))) void render_kernel(RenderParams P)
 {
     extern __shared__ float4 lds_raw[];
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
         stamp_trav += __builtin_amdgcn_s_memtime() - st0;
         stamp_trips++;
 #endif
-        shade(L, P, V, h);
+        if (kLegacy) spheres_hit(P, L.ro, L.rd, 0.001f, h);
+        shade<kLegacy>(L, P, V, h);
     }
 
     if (in_frame) write_pixel(P, L.col, pixel_index);
@@ -337,6 +338,12 @@ struct pt_device {
     int W = 0, H = 0;
     uint8_t *rgb = nullptr, *yuv = nullptr;
     unsigned block_x = 8, block_y = 8;
+    // extension: legacy material classes + spheres (pt_set_legacy_scene), applied by the next upload
+    std::vector<pt_legacy_material> legacy_next;
+    std::vector<pt_sphere> spheres_next;
+    float4 *d_legacy = nullptr, *d_spheres = nullptr;
+    int n_spheres = 0;
+    bool legacy_on = false;       // the uploaded scene uses a legacy material or a sphere
     // adaptive tile schedule
     int tile_schedule = 1;        // 0 raster order, 1 cost-ordered from the previous launch of the same task
     std::vector<TileSchedule *> schedules;
@@ -354,6 +361,7 @@ struct pt_device {
 static int choose_walk(const pt_device *d)
 {
     const bool mask_ok = d->n_pairs <= 64, stack_ok = d->n_pairs <= 4096;
+    if (d->legacy_on) return d->force_walk <= 0 ? 0 : -1;      // the extension is compiled into the per-lane walk only
     if (d->sah) return 3;                     // the SAH tree has its own walk
     if (d->force_walk == 0) return 0;
     if (d->force_walk == 1) return mask_ok ? 1 : -1;
@@ -381,7 +389,8 @@ static void free_scene(pt_device *d)
 {
     (void)hipFree(d->d_nodes); (void)hipFree(d->d_tris); (void)hipFree(d->d_shade);
     (void)hipFree(d->d_lights); (void)hipFree(d->d_mats); (void)hipFree(d->d_texs);
-    (void)hipFree(d->d_texels);
+    (void)hipFree(d->d_texels); (void)hipFree(d->d_legacy); (void)hipFree(d->d_spheres);
+    d->d_legacy = nullptr; d->d_spheres = nullptr; d->n_spheres = 0; d->legacy_on = false;
     d->d_nodes = nullptr; d->d_tris = nullptr; d->d_shade = nullptr; d->d_lights = nullptr;
     d->d_mats = nullptr; d->d_texs = nullptr; d->d_texels = nullptr;
     d->has_scene = false;
@@ -495,8 +504,25 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
         const float *e = mats[tris[i].materialIdx].emissiveFactor;
         if (e[0] > 0.0001f || e[1] > 0.0001f || e[2] > 0.0001f) lights.push_back((int)i);   // :305
     }
-    if (lights.empty())
-        return set_error(PT_ERR_NO_LIGHTS, "scene has no emissive face: the reference's light sampling dereferences an empty list (hitable_list.h:23-26)");
+    // extension: legacy material kinds / spheres for this upload
+    if (!dev->legacy_next.empty() && dev->legacy_next.size() != m)
+        return set_error(PT_ERR_INVALID, "pt_set_legacy_scene: one legacy record per material is required");
+    for (const pt_sphere &sp : dev->spheres_next)
+        if (sp.materialIdx < 0 || (size_t)sp.materialIdx >= m) return set_error(PT_ERR_INVALID, "sphere material index out of range");
+    bool legacy_on = !dev->spheres_next.empty();
+    for (const pt_legacy_material &lm : dev->legacy_next) legacy_on = legacy_on || lm.kind != 0;
+    auto is_universal = [&](int mat) { return dev->legacy_next.empty() || dev->legacy_next[(size_t)mat].kind == 0; };
+    if (lights.empty()) {
+        // the live material samples the light list on every bounce (hitable_list.h:23-26): an empty list
+        // is only tolerable when nothing in the scene uses that material
+        bool any_universal = false;
+        for (size_t i = 0; i < n; i++) any_universal = any_universal || is_universal(tris[i].materialIdx);
+        for (const pt_sphere &sp : dev->spheres_next) any_universal = any_universal || is_universal(sp.materialIdx);
+        if (any_universal)
+            return set_error(PT_ERR_NO_LIGHTS, "scene has no emissive face: the reference's light sampling dereferences an empty list (hitable_list.h:23-26)");
+    }
+    if (legacy_on && dev->bvh_mode == 1)
+        return set_error(PT_ERR_UNSUPPORTED, "the legacy-material / sphere extension runs on the reference tree only (pt_set_bvh_mode 0)");
 
     // create_world, DevicePathTracer.h:134-146 -> BVH::BVH, bvh.h:20-33, on the host
     const bool sah = dev->bvh_mode == 1;
@@ -626,6 +652,25 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
     if ((st = upload_vec(mrec, &dev->d_mats)) != PT_OK) return st;
     if ((st = upload_vec(tdesc, &dev->d_texs)) != PT_OK) return st;
     if ((st = upload_vec(pool, &dev->d_texels)) != PT_OK) return st;
+    if (legacy_on) {
+        std::vector<float4> lrec4(2 * m), srec4(2 * std::max<size_t>(dev->spheres_next.size(), 1));
+        for (size_t i = 0; i < m; i++) {
+            pt_legacy_material lm;
+            memset(&lm, 0, sizeof lm);
+            if (!dev->legacy_next.empty()) lm = dev->legacy_next[i];
+            lrec4[2 * i] = make_float4(lm.albedo[0], lm.albedo[1], lm.albedo[2], lm.param);
+            lrec4[2 * i + 1] = make_float4(__builtin_bit_cast(float, (int32_t)lm.kind), 0.0f, 0.0f, 0.0f);
+        }
+        for (size_t i = 0; i < dev->spheres_next.size(); i++) {
+            const pt_sphere &sp = dev->spheres_next[i];
+            srec4[2 * i] = make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius);
+            srec4[2 * i + 1] = make_float4(__builtin_bit_cast(float, (int32_t)sp.materialIdx), 0.0f, 0.0f, 0.0f);
+        }
+        if ((st = upload_vec(lrec4, &dev->d_legacy)) != PT_OK) return st;
+        if ((st = upload_vec(srec4, &dev->d_spheres)) != PT_OK) return st;
+        dev->n_spheres = (int)dev->spheres_next.size();
+    }
+    dev->legacy_on = legacy_on;
     dev->bvh = std::move(bvh);
     dev->light_faces = lights;
     dev->n_lights = (int)lights.size();
@@ -639,7 +684,7 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
     dev->packed_queue = n < 65536;
     dev->sah = sah;
     dev->sah_stack = sah ? sahbvh.max_stack : 0;
-    dev->walk = choose_walk(dev);
+    dev->walk = std::max(choose_walk(dev), 0);
     dev->queue_entries = (int)std::min<uint32_t>(std::max<uint32_t>(dev->bvh.leaves + 1, 4), 12);
     dev->has_scene = true;
     return PT_OK;
@@ -669,6 +714,20 @@ pt_status pt_set_bvh_mode(pt_device *dev, int mode)
     clear_error();
     if (!dev || mode < 0 || mode > 1) return set_error(PT_ERR_INVALID, "bvh mode must be 0 (reference topology) or 1 (SAH tree)");
     dev->bvh_mode = mode;
+    return PT_OK;
+}
+
+pt_status pt_set_legacy_scene(pt_device *dev, const pt_legacy_material *materials, size_t n_materials,
+                              const pt_sphere *spheres, size_t n_spheres)
+{
+    clear_error();
+    if (!dev || (n_materials && !materials) || (n_spheres && !spheres)) return set_error(PT_ERR_INVALID, "null argument");
+    for (size_t i = 0; i < n_materials; i++)
+        if (materials[i].kind < 0 || materials[i].kind > 4) return set_error(PT_ERR_INVALID, "legacy material kind must be 0..4");
+    for (size_t i = 0; i < n_spheres; i++)
+        if (!(spheres[i].radius == spheres[i].radius)) return set_error(PT_ERR_INVALID, "sphere radius is NaN");
+    dev->legacy_next.assign(materials, materials + n_materials);
+    dev->spheres_next.assign(spheres, spheres + n_spheres);
     return PT_OK;
 }
 
@@ -736,8 +795,9 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.sah = dev->sah ? 1 : 0;
     P.spec_pct = dev->spec_pct;
     P.tile_order = nullptr; P.tile_cost = nullptr;
+    P.legacy_mats = dev->d_legacy; P.spheres = dev->d_spheres; P.n_spheres = dev->n_spheres;
     if (dev->sah) P.stack_entries = (int)dev->sah_stack;
-    P.queue_dwords = dev->packed_queue ? 1 : 2;
+    P.queue_dwords = (dev->packed_queue && !dev->legacy_on) ? 1 : 2;      // the extension kernel uses the unpacked queue
     P.n_mats = (int)dev->n_mats;
     // shading tables in LDS when they are small (Cornell box: 1.9 KB)
     P.shade_lds = (dev->n_tris * 48 + dev->n_mats * 48 + (size_t)dev->n_lights * 80) <= 16 * 1024 ? 1 : 0;
@@ -793,7 +853,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     long long tiles = (long long)P.tiles_x * P.tiles_y;
     unsigned blocks = (unsigned)((tiles + dev::kWavesPerBlock - 1) / dev::kWavesPerBlock);
     const int walk = dev->walk;
-    const bool stage = dev->lds_scene && walk == 0, packed = dev->packed_queue;
+    const bool stage = dev->lds_scene && walk == 0 && !dev->legacy_on, packed = dev->packed_queue && !dev->legacy_on;
     if (walk != 0) P.queue_entries = 0;
     if (walk == 1) P.stack_entries = 0;
     size_t lds = lds_bytes(P, dev::kBlock, stage);
@@ -823,6 +883,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     else if (walk == 3) hipLaunchKernelGGL((dev::render_kernel<false, true, 3>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (walk == 1) hipLaunchKernelGGL((dev::render_kernel<false, true, 1>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (walk == 2) hipLaunchKernelGGL((dev::render_kernel<false, true, 2>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (dev->legacy_on) hipLaunchKernelGGL((dev::render_kernel<false, false, 0, true>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (stage && packed) hipLaunchKernelGGL((dev::render_kernel<true, true, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (stage) hipLaunchKernelGGL((dev::render_kernel<true, false, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (packed) hipLaunchKernelGGL((dev::render_kernel<false, true, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);

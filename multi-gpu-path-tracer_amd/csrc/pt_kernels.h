@@ -19,6 +19,9 @@ struct RenderParams {
     const MatRec *mats;
     const TexDesc *texs;
     const float *texels;
+    const float4 *legacy_mats;        // extension (pt_set_legacy_scene): 2 x float4 per material {albedo, param}, {kind}
+    const float4 *spheres;            // extension: 2 x float4 per sphere {centre, radius}, {material}
+    int n_spheres;
     uint8_t *rgb;
     uint8_t *yuv;
     unsigned long long *counters;     // 5 x u64: paths, segments, box, tri, light

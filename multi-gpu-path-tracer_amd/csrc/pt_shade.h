@@ -162,22 +162,159 @@ __device__ __forceinline__ bool start_path(PathState &L, const RenderParams &P, 
     return true;
 }
 
+// ---- extension: the reference's legacy material classes and sphere ----------------------
+// Off unless pt_set_legacy_scene was called; compiled only into render_kernel<..., kLegacy = true>.  No
+// integrator of the reference at HEAD calls these classes, so the loop around them (shade<true>) is this
+// project's choice -- the classic scatter / emitted loop their signatures were written for -- and, like
+// the rest, parity-unpinned; the kernel and oracle/pt_oracle.c agree bit for bit.
+
+// sphere::hit, sphere.h:21-50 (the double promotions there do not change a bit, see the oracle).
+__device__ __forceinline__ bool sphere_hit(float4 s, v3 o, v3 d, float tmin, float tmax, float &t_out)
+{
+    const v3 center = mk3(s.x, s.y, s.z);
+    const v3 oc = o - center;
+    const float a = dot(d, d);
+    const float b = 2.0f * dot(oc, d);
+    const float cc = dot(oc, oc) - s.w * s.w;
+    const float discriminant = b * b - 4 * a * cc;
+    if (discriminant > 0) {
+        const float root = sqrtf(discriminant);
+        float temp = (-b - root) / (2.0f * a);
+        if (temp < tmax && temp > tmin) { t_out = temp; return true; }
+        temp = (-b + root) / (2.0f * a);
+        if (temp < tmax && temp > tmin) { t_out = temp; return true; }
+    }
+    return false;
+}
+
+// Spheres are tested after the BVH like members of a hitable_list: the closest hit so far shrinks the
+// interval.  A sphere hit is reported as slot = -2 - index.
+__device__ __forceinline__ void spheres_hit(const RenderParams &P, v3 o, v3 d, float tmin, Hit &h)
+{
+    float closest = h.slot >= 0 ? h.t : 3.402823466e+38f;
+    for (int i = 0; i < P.n_spheres; i++) {
+        float t;
+        if (sphere_hit(P.spheres[2 * i], o, d, tmin, closest, t)) { h.t = t; h.u = h.v = 0.0f; h.slot = -2 - i; closest = t; }
+    }
+}
+
+__device__ __forceinline__ v3 random_in_unit_sphere(xorwow &rng)            // helper_math.h:1511-1518
+{
+    v3 p;
+    do {
+        const float x = xorwow_uniform(rng), y = xorwow_uniform(rng), z = xorwow_uniform(rng);
+        p = mk3(x, y, z) * 2.0f - mk3(1.0f, 1.0f, 1.0f);
+    } while (dot(p, p) >= 1.0f);
+    return p;
+}
+__device__ __forceinline__ v3 reflect(v3 i, v3 n) { return i - (n * 2.0f) * dot(n, i); }   // :1429-1432
+
+// material::scatter of lambertian / metal / dielectric / diffuse_light (material.h:110-217).
+// False = the path ends at this hit.
+__device__ __forceinline__ bool legacy_scatter(PathState &L, int kind, v3 albedo, float param, v3 normal, v3 p,
+                                               v3 &attenuation, v3 &out_dir)
+{
+    if (kind == 1) {                                                     // lambertian
+        v3 dir = normal + random_in_unit_sphere(L.rng);
+        if (fabsf(dir.x) <= 1e-8f && fabsf(dir.y) <= 1e-8f && fabsf(dir.z) <= 1e-8f) dir = normal;   // near_zero
+        out_dir = dir; attenuation = albedo;
+        return true;
+    }
+    if (kind == 2) {                                                     // metal, fuzz clamped by the ctor
+        const float fuzz = param < 1 ? param : 1;
+        const v3 reflected = reflect(normalize(L.rd), normal);
+        out_dir = reflected + random_in_unit_sphere(L.rng) * fuzz;
+        attenuation = albedo;
+        return dot(out_dir, normal) > 0;
+    }
+    if (kind == 3) {                                                     // dielectric
+        const float ir = param;
+        const v3 reflected = reflect(L.rd, normal);
+        v3 outward, refracted = mk3(0.0f, 0.0f, 0.0f);
+        float ni_over_nt, reflect_prob, cosine;
+        attenuation = mk3(1.0f, 1.0f, 1.0f);
+        if (dot(L.rd, normal) > 0.0f) {
+            outward = mk3(-normal.x, -normal.y, -normal.z);
+            ni_over_nt = ir;
+            cosine = dot(L.rd, normal) / length(L.rd);
+            cosine = sqrtf(1.0f - ir * ir * (1 - cosine * cosine));
+        } else {
+            outward = normal;
+            ni_over_nt = 1.0f / ir;
+            cosine = -dot(L.rd, normal) / length(L.rd);
+        }
+        bool can_refract = false;
+        {                                                                // refract, helper_math.cu:7-17
+            const v3 uv = normalize(L.rd);
+            const float dt = dot(uv, outward);
+            const float discriminant = 1.0f - ni_over_nt * ni_over_nt * (1 - dt * dt);
+            if (discriminant > 0) {
+                refracted = (uv - outward * dt) * ni_over_nt - outward * sqrtf(discriminant);
+                can_refract = true;
+            }
+        }
+        if (can_refract) {                                               // schlick_approx, material.h:10-14; x^5 = ((x*x)*(x*x))*x
+            float r0 = (1 - ir) / (1 + ir);
+            r0 = r0 * r0;
+            const float x = 1 - cosine, x2 = x * x;
+            reflect_prob = r0 + (1 - r0) * ((x2 * x2) * x);
+        } else reflect_prob = 1.0f;
+        out_dir = (xorwow_uniform(L.rng) < reflect_prob) ? reflected : refracted;
+        return true;
+    }
+    return false;                                                        // diffuse_light: material::scatter
+}
+
 // What camera::ray_color does with the result of one BVH::hit (camera.h:55-80): miss, emissive
 // hit, or a scattering bounce that sets up the next ray segment.
+template <bool kLegacy = false>
 __device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const ShadeView &V, const Hit &h)
 {
-    if (h.slot < 0) {
+    if (h.slot == -1) {
         L.col = L.col + mk3(0.0f, 0.0f, 0.0f) * L.atten;                // camera.h:78-79
         L.need_new = true;
         return;
     }
-    // hit_record completion, triangle.h:100-108
-    const float4 tc = V.shade[3 * (size_t)h.slot + 2];
-    v3 normal = mk3(tc.x, tc.y, tc.z);
+    // hit_record completion, triangle.h:100-108 (sphere.h:33-36 for a sphere of the extension)
+    v3 normal;
     v3 p = L.ro + h.t * L.rd;
-    const float4 *sp4 = V.shade + 3 * (size_t)h.slot;
-    float4 s0 = sp4[0], s1 = sp4[1];
-    int mat = __float_as_int(s1.z);
+    float4 s0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), s1 = s0;
+    int mat;
+    if (kLegacy && h.slot < -1) {
+        const int si = -2 - h.slot;
+        const float4 sph = P.spheres[2 * si];
+        normal = (p - mk3(sph.x, sph.y, sph.z)) / sph.w;
+        mat = __float_as_int(P.spheres[2 * si + 1].x);
+    } else {
+        const float4 tc = V.shade[3 * (size_t)h.slot + 2];
+        normal = mk3(tc.x, tc.y, tc.z);
+        const float4 *sp4 = V.shade + 3 * (size_t)h.slot;
+        s0 = sp4[0]; s1 = sp4[1];
+        mat = __float_as_int(s1.z);
+    }
+    if (kLegacy) {
+        const float4 l0 = P.legacy_mats[2 * (size_t)mat];
+        const int kind = __float_as_int(P.legacy_mats[2 * (size_t)mat + 1].x);
+        if (kind != 0) {
+            // end on emitters and absorbed rays, otherwise multiply the throughput and follow the scattered ray
+            v3 attenuation = mk3(0.0f, 0.0f, 0.0f), dir = L.rd;
+            const v3 albedo = mk3(l0.x, l0.y, l0.z);
+            if (!legacy_scatter(L, kind, albedo, l0.w, normal, p, attenuation, dir)) {
+                const v3 emitted = kind == 4 ? albedo : mk3(0.0f, 0.0f, 0.0f);
+                L.col = L.col + L.atten * emitted;
+                L.need_new = true;
+                return;
+            }
+            L.atten = L.atten * attenuation;
+            L.ro = p; L.rd = dir;
+            L.bounce++;
+            if (L.bounce >= P.depth) {
+                L.col = L.col + mk3(0.0f, 0.0f, 0.0f);
+                L.need_new = true;
+            }
+            return;
+        }
+    }
     const float4 *mp = V.mats + 3 * (size_t)mat;
     float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
     int baseTex = __float_as_int(m0.w), emisTex = __float_as_int(m1.w);

@@ -218,7 +218,8 @@ class DevicePathTracer:
     """DevicePathTracer (DevicePathTracer.h:167-392) on one MI355X through the C ABI."""
 
     def __init__(self, device_idx: int, samplesPerPixel: int, recursionDepth: int, threadBlockSize,
-                 hostScene: HostScene, framebuffer: Framebuffer, cameraConfig: CameraConfig):
+                 hostScene: HostScene, framebuffer: Framebuffer, cameraConfig: CameraConfig,
+                 legacyMaterials=None, spheres=None):
         self.device_idx_ = device_idx
         self.samplesPerPixel_ = samplesPerPixel
         self.recursionDepth_ = recursionDepth
@@ -230,6 +231,8 @@ class DevicePathTracer:
         capi.check(capi.lib().pt_device_create(device_idx, C.byref(h)))
         self._h = h
         capi.check(capi.lib().pt_set_thread_block_size(self._h, *self.threadBlockSize_))
+        if legacyMaterials is not None or spheres is not None:      # extension, before the first upload
+            self.setLegacyScene(legacyMaterials, spheres, reload=False)
         self.reloadWorld()
         self.reloadCamera()
         self.setFramebuffer(framebuffer)
@@ -287,6 +290,16 @@ class DevicePathTracer:
     def setThreadBlockSize(self, threadBlockSize):
         self.threadBlockSize_ = tuple(threadBlockSize)
         capi.check(capi.lib().pt_set_thread_block_size(self._h, *self.threadBlockSize_))
+
+    def setLegacyScene(self, materials=None, spheres=None, reload: bool = True):
+        """EXTENSION (include/pt_amd.h pt_set_legacy_scene): one LEGACY_MATERIAL_DTYPE record per material
+        (kind 0 keeps the UniversalMaterial) and SPHERE_DTYPE records; None / empty switches it off."""
+        m = np.ascontiguousarray(materials if materials is not None else [], dtype=capi.LEGACY_MATERIAL_DTYPE)
+        sp = np.ascontiguousarray(spheres if spheres is not None else [], dtype=capi.SPHERE_DTYPE)
+        capi.check(capi.lib().pt_set_legacy_scene(self._h, capi.np_ptr(m) if len(m) else None, len(m),
+                                                  capi.np_ptr(sp) if len(sp) else None, len(sp)))
+        if reload:
+            self.reloadWorld()
 
     def setBvhMode(self, mode: int, reload: bool = True):
         """0 = reference-topology BVH (default), 1 = opt-in SAH tree; takes effect at reloadWorld()."""

@@ -55,6 +55,8 @@ def lib():
         L.ptor_scene_create.restype = C.c_int
         L.ptor_scene_create.argtypes = [vp, C.c_int, vp, C.c_int, C.POINTER(_Texture), C.c_int, C.POINTER(vp)]
         L.ptor_scene_destroy.argtypes = [vp]
+        L.ptor_scene_set_legacy.restype = C.c_int
+        L.ptor_scene_set_legacy.argtypes = [vp, vp, C.c_int, vp, C.c_int]
         L.ptor_scene_node_count.restype = C.c_uint32
         L.ptor_scene_node_count.argtypes = [vp]
         L.ptor_scene_light_count.restype = C.c_int
@@ -102,6 +104,18 @@ class OracleScene:
                 self._h = None
         except Exception:
             pass
+
+    def set_legacy(self, materials=None, spheres=None):
+        """Extension: legacy material kinds {kind, albedo[3], param} per material and spheres
+        {center[3], radius, materialIdx}; None switches it off."""
+        lm = np.dtype([("kind", np.int32), ("albedo", np.float32, 3), ("param", np.float32)])
+        sd = np.dtype([("center", np.float32, 3), ("radius", np.float32), ("materialIdx", np.int32)])
+        m = np.ascontiguousarray(materials if materials is not None else [], dtype=lm)
+        sp = np.ascontiguousarray(spheres if spheres is not None else [], dtype=sd)
+        rc = lib().ptor_scene_set_legacy(self._h, m.ctypes.data if len(m) else None, len(m),
+                                         sp.ctypes.data if len(sp) else None, len(sp))
+        if rc != 0:
+            raise RuntimeError("ptor_scene_set_legacy failed: %d" % rc)
 
     def bvh(self):
         n = lib().ptor_scene_node_count(self._h)

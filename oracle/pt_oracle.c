@@ -67,6 +67,15 @@ typedef struct {
     uint64_t nan_pixels;   /* pixels whose accumulated colour has a NaN channel          */
 } ptor_counters;
 
+/* Extension (off unless ptor_scene_set_legacy is called): the reference's legacy material
+ * classes and sphere.  No integrator of the reference at HEAD calls them, so the loop that drives them
+ * below is this project's choice (the classic scatter/emitted loop their signatures were written for);
+ * PARITY UNPINNED, like the rest of this oracle.  kind: 0 = UniversalMaterial (the live path),
+ * 1 lambertian(albedo) material.h:110-127, 2 metal(albedo, fuzz) :130-144, 3 dielectric(ir) :146-178,
+ * 4 diffuse_light(color) :210-217.                                                              */
+typedef struct { int kind; float albedo[3]; float param; } ptor_legacy_material;
+typedef struct { float center[3]; float radius; int materialIdx; } ptor_sphere;   /* sphere.h:8-20 */
+
 typedef struct { float x, y, z; } f3;
 
 static inline f3 mk3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
@@ -203,6 +212,8 @@ typedef struct ptor_scene {
     int   *lights; int nlights;       /* face indices, DevicePathTracer.h:304-307 */
     onode *nodes;  uint32_t nodesUsed;
     int   *indices;
+    ptor_legacy_material *legacy;     /* nmats entries, or NULL: every material is universal */
+    ptor_sphere *spheres; int nspheres;
 } ptor_scene;
 
 /* ------------------------------------------------------------------- aabb / bvh ---- */
@@ -373,7 +384,29 @@ void ptor_scene_destroy(ptor_scene *sc)
     if (!sc) return;
     for (int i = 0; i < sc->ntexs; i++) free(sc->texs[i].data);
     free(sc->texs); free(sc->mats); free(sc->tris); free(sc->lights);
-    free(sc->nodes); free(sc->indices); free(sc);
+    free(sc->nodes); free(sc->indices); free(sc->legacy); free(sc->spheres); free(sc);
+}
+
+/* Legacy materials (one entry per material, kind 0 keeps the universal material) and spheres, which are
+ * tested after the BVH like the members of a hitable_list (closest so far shrinks the interval). */
+int ptor_scene_set_legacy(ptor_scene *sc, const ptor_legacy_material *ext, int next,
+                          const ptor_sphere *spheres, int nspheres)
+{
+    if (!sc || (ext && next != sc->nmats) || nspheres < 0 || (nspheres && !spheres)) return 1;
+    free(sc->legacy); sc->legacy = NULL;
+    free(sc->spheres); sc->spheres = NULL; sc->nspheres = 0;
+    if (ext) {
+        for (int i = 0; i < next; i++) if (ext[i].kind < 0 || ext[i].kind > 4) return 2;
+        sc->legacy = (ptor_legacy_material *)malloc(sizeof(*ext) * (size_t)next);
+        memcpy(sc->legacy, ext, sizeof(*ext) * (size_t)next);
+    }
+    if (nspheres) {
+        for (int i = 0; i < nspheres; i++) if (spheres[i].materialIdx < 0 || spheres[i].materialIdx >= sc->nmats) return 3;
+        sc->spheres = (ptor_sphere *)malloc(sizeof(*spheres) * (size_t)nspheres);
+        memcpy(sc->spheres, spheres, sizeof(*spheres) * (size_t)nspheres);
+        sc->nspheres = nspheres;
+    }
+    return 0;
 }
 
 /* Introspection for known-answer tests. Node record = 6 floats + 4 u32 = 40 B. */
@@ -568,6 +601,130 @@ static f3 tri_random(octx *c, const otri *tr, f3 o)
 /* camera.h:49-83 ray_color, with material.h:52-91 (scatter / emitted / scattering_pdf),
  * pdf.h:13-72 (cosine_pdf, hitable_list_pdf, mixture_pdf) and hitable_list.h:16-26
  * flattened in call order.  Returns the radiance of one path.                            */
+/* sphere::hit, sphere.h:21-50.  `2.0 * x` and `/ (2.0 * a)` promote to double in the source; doubling is
+ * exact and a float quotient computed in double and rounded back is the correctly rounded float quotient,
+ * so plain float arithmetic gives the same bits.  texCoord is not written there: (0, 0) here. */
+static int sphere_hit(const ptor_sphere *s, const oray *r, float tmin, float tmax, orec *rec)
+{
+    f3 center = mk3(s->center[0], s->center[1], s->center[2]);
+    f3 oc = sub3(r->o, center);
+    float a = dot3(r->d, r->d);
+    float b = 2.0f * dot3(oc, r->d);
+    float cc = dot3(oc, oc) - s->radius * s->radius;
+    float discriminant = b * b - 4 * a * cc;
+    if (discriminant > 0) {
+        float root = sqrtf(discriminant);
+        for (int k = 0; k < 2; k++) {
+            float temp = (k == 0 ? (-b - root) : (-b + root)) / (2.0f * a);
+            if (temp < tmax && temp > tmin) {
+                rec->t = temp;
+                rec->p = add3(r->o, scale3(r->d, temp));
+                rec->normal = div3s(sub3(rec->p, center), s->radius);
+                rec->mat = s->materialIdx;
+                rec->tu = rec->tv = 0.0f;
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+
+/* The world of the extension: the BVH, then every sphere against the closest hit so far. */
+static int world_hit(octx *c, const oray *r, float tmin, float tmax, orec *rec, int *err)
+{
+    int found = bvh_hit(c, r, tmin, tmax, rec, err);
+    float closest = found ? rec->t : tmax;
+    for (int i = 0; i < c->sc->nspheres; i++) {
+        orec tmp;
+        if (sphere_hit(&c->sc->spheres[i], r, tmin, closest, &tmp)) { *rec = tmp; closest = tmp.t; found = 1; }
+    }
+    return found;
+}
+
+/* helper_math.h:1511-1518: rejection sampling in the unit ball, three draws per try. */
+static f3 random_in_unit_sphere(octx *c)
+{
+    f3 p;
+    do {
+        float x = U(c), y = U(c), z = U(c);
+        p = sub3(scale3(mk3(x, y, z), 2.0f), mk3(1.0f, 1.0f, 1.0f));
+    } while (dot3(p, p) >= 1.0f);
+    return p;
+}
+
+static f3 reflect3(f3 i, f3 n) { return sub3(i, scale3(scale3(n, 2.0f), dot3(n, i))); }   /* helper_math.h:1429-1432: i - 2.0f*n*dot(n,i) */
+
+/* helper_math.cu:7-17 */
+static int refract3(f3 v, f3 n, float ni_over_nt, f3 *refracted)
+{
+    f3 uv = normalize3(v);
+    float dt = dot3(uv, n);
+    float discriminant = 1.0f - ni_over_nt * ni_over_nt * (1 - dt * dt);
+    if (discriminant > 0) {
+        *refracted = sub3(scale3(sub3(uv, scale3(n, dt)), ni_over_nt), scale3(n, sqrtf(discriminant)));
+        return 1;
+    }
+    return 0;
+}
+
+/* material.h:10-14; pow(x, 5) is evaluated as ((x*x)*(x*x))*x here and in the kernel (CUDA's pow is not
+ * reproducible off NVIDIA hardware). */
+static float schlick_approx(float cosine, float ref_idx)
+{
+    float r0 = (1 - ref_idx) / (1 + ref_idx);
+    r0 = r0 * r0;
+    float x = 1 - cosine, x2 = x * x;
+    return r0 + (1 - r0) * ((x2 * x2) * x);
+}
+
+/* material::scatter of the legacy classes.  Returns 0 when the path ends at this hit. */
+static int legacy_scatter(octx *c, const ptor_legacy_material *m, const oray *r_in, const orec *rec,
+                          f3 *attenuation, oray *scattered)
+{
+    f3 albedo = mk3(m->albedo[0], m->albedo[1], m->albedo[2]);
+    switch (m->kind) {
+    case 1: {                                                        /* lambertian, material.h:113-124 */
+        f3 dir = add3(rec->normal, random_in_unit_sphere(c));
+        if (fabsf(dir.x) <= 1e-8f && fabsf(dir.y) <= 1e-8f && fabsf(dir.z) <= 1e-8f) dir = rec->normal;   /* near_zero: < 1e-8 (double) */
+        scattered->o = rec->p; scattered->d = dir;
+        *attenuation = albedo;
+        return 1;
+    }
+    case 2: {                                                        /* metal, :132-140; fuzz clamped by the ctor */
+        float fuzz = m->param < 1 ? m->param : 1;
+        f3 reflected = reflect3(normalize3(r_in->d), rec->normal);
+        scattered->o = rec->p;
+        scattered->d = add3(reflected, scale3(random_in_unit_sphere(c), fuzz));
+        *attenuation = albedo;
+        return dot3(scattered->d, rec->normal) > 0;
+    }
+    case 3: {                                                        /* dielectric, :148-178 */
+        float ir = m->param;
+        f3 outward_normal, refracted = mk3(0.0f, 0.0f, 0.0f);
+        f3 reflected = reflect3(r_in->d, rec->normal);
+        float ni_over_nt, reflect_prob, cosine;
+        *attenuation = mk3(1.0f, 1.0f, 1.0f);
+        if (dot3(r_in->d, rec->normal) > 0.0f) {
+            outward_normal = mk3(-rec->normal.x, -rec->normal.y, -rec->normal.z);
+            ni_over_nt = ir;
+            cosine = dot3(r_in->d, rec->normal) / length3(r_in->d);
+            cosine = sqrtf(1.0f - ir * ir * (1 - cosine * cosine));
+        } else {
+            outward_normal = rec->normal;
+            ni_over_nt = 1.0f / ir;
+            cosine = -dot3(r_in->d, rec->normal) / length3(r_in->d);
+        }
+        if (refract3(r_in->d, outward_normal, ni_over_nt, &refracted)) reflect_prob = schlick_approx(cosine, ir);
+        else reflect_prob = 1.0f;
+        scattered->o = rec->p;
+        scattered->d = (U(c) < reflect_prob) ? reflected : refracted;
+        return 1;
+    }
+    default:                                                         /* diffuse_light: material::scatter, :31-34 */
+        return 0;
+    }
+}
+
 static f3 ray_color(octx *c, oray ray, unsigned depth, int *err)
 {
     const ptor_scene *sc = c->sc;
@@ -575,8 +732,22 @@ static f3 ray_color(octx *c, oray ray, unsigned depth, int *err)
     for (unsigned i = 0; i < depth; i++) {
         orec rec; memset(&rec, 0, sizeof rec);
         c->cnt->segments++;
-        if (bvh_hit(c, &ray, 0.001f, FLT_MAX, &rec, err)) {
+        if ((sc->nspheres ? world_hit(c, &ray, 0.001f, FLT_MAX, &rec, err) : bvh_hit(c, &ray, 0.001f, FLT_MAX, &rec, err))) {
             const omat *m = &sc->mats[rec.mat];
+            if (sc->legacy && sc->legacy[rec.mat].kind != 0) {
+                /* the loop the legacy signatures were written for: end on emitters and absorbed rays,
+                 * otherwise multiply the throughput and follow the scattered ray */
+                const ptor_legacy_material *lm = &sc->legacy[rec.mat];
+                f3 attenuation = mk3(0.0f, 0.0f, 0.0f);
+                oray scattered = ray;
+                if (!legacy_scatter(c, lm, &ray, &rec, &attenuation, &scattered)) {
+                    f3 emitted = lm->kind == 4 ? mk3(lm->albedo[0], lm->albedo[1], lm->albedo[2]) : mk3(0.0f, 0.0f, 0.0f);
+                    return mul3(atten, emitted);
+                }
+                atten = mul3(atten, attenuation);
+                ray = scattered;
+                continue;
+            }
             /* material.h:80-86 emitted */
             f3 emitted;
             if (m->emisTex >= 0) emitted = scale3(mul3(tex_value(&sc->texs[m->emisTex], rec.tu, rec.tv), m->emissive), 50);
@@ -661,7 +832,12 @@ int ptor_render(const ptor_scene *sc, const ptor_camera *cfg, int W, int H,
                 uint8_t *rgb, uint8_t *yuv, ptor_counters *cnt)
 {
     ptor_counters local; memset(&local, 0, sizeof local);
-    if (sc->nlights <= 0) return 2;       /* reference: list[idx] of an empty list = UB */
+    if (sc->nlights <= 0) {               /* reference: list[idx] of an empty list = UB ... */
+        int any_universal = 0;            /* ... unless (extension) nothing in the scene uses the live material */
+        for (int i = 0; i < sc->ntris; i++) any_universal |= !sc->legacy || sc->legacy[sc->tris[i].mat].kind == 0;
+        for (int i = 0; i < sc->nspheres; i++) any_universal |= !sc->legacy || sc->legacy[sc->spheres[i].materialIdx].kind == 0;
+        if (any_universal) return 2;
+    }
     ocam cam = camera_setup(cfg);
     int err = 0;
     for (int j = 0; j < task->height; j++) {

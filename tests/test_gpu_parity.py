@@ -317,3 +317,107 @@ def test_random_scenes_bit_exact_in_every_walk(pt, ob, gpu_device, seed):
     modes = [1, 3] + ([2] if info["nodes"] - info["leaves"] <= 64 else [])
     for mode in modes:
         _assert_same(_render_gpu(pt, scene, cam, W, H, spp, depth, mode=mode), ref)
+
+
+# ---- extension: legacy material classes + spheres (pt_set_legacy_scene) -----------------
+
+def _legacy_records(pt, kinds):
+    rec = np.zeros(len(kinds), pt.capi.LEGACY_MATERIAL_DTYPE)
+    for i, (kind, albedo, param) in enumerate(kinds):
+        rec[i]["kind"] = kind; rec[i]["albedo"] = albedo; rec[i]["param"] = param
+    return rec
+
+
+def _render_gpu_legacy(pt, scene, legacy, spheres, camera, W, H, spp, depth):
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, pt.CameraConfig(camera[0], camera[1], camera[2], camera[3]))
+    tr.setLegacyScene(legacy, spheres)
+    tr.resetCounters()
+    tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+    got = (fb.rgb_host().copy(), fb.yuv_host().copy(), tr.readCounters())
+    # switching the extension off again restores the plain path
+    tr.setLegacyScene(None, None)
+    tr.resetCounters()
+    tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+    plain = (fb.rgb_host().copy(), fb.yuv_host().copy(), tr.readCounters())
+    tr.close()
+    return got, plain
+
+
+def test_legacy_materials_in_the_cornell_box_match_the_oracle(pt, ob, box_scene, box_oracle, gpu_device):
+    """Cornell box with the walls re-declared as legacy lambertian / metal / dielectric where their names
+    say so, one glass and one mirror sphere added; the light stays the live emissive material, so universal
+    and legacy materials meet on the same paths.  Kernel == oracle, bytes and counters."""
+    W, H, spp, depth = 96, 64, 8, 8
+    n = len(box_scene.materials)
+    kinds = []
+    for i in range(n):
+        name = box_scene.material_names[i]
+        emissive = box_scene.materials["emissiveFactor"][i].max() > 0
+        if emissive: kinds.append((0, (0, 0, 0), 0.0))                               # the light: live material
+        elif i % 3 == 0: kinds.append((1, tuple(box_scene.materials["baseColor"][i]), 0.0))   # lambertian
+        elif i % 3 == 1: kinds.append((2, (0.8, 0.85, 0.9), 0.15))                   # fuzzy metal
+        else: kinds.append((0, (0, 0, 0), 0.0))                                      # stays universal
+    legacy = _legacy_records(pt, kinds)
+    # add glass + mirror materials? spheres reuse existing material slots: pick a metal and make slot 0.. dielectric
+    di = next(i for i, k in enumerate(kinds) if k[0] == 1)
+    legacy[di]["kind"] = 3; legacy[di]["param"] = 1.5                               # one lambertian slot becomes glass
+    me = next(i for i, k in enumerate(kinds) if k[0] == 2)
+    spheres = np.zeros(2, pt.capi.SPHERE_DTYPE)
+    spheres[0] = ((-180.0, 120.0, 250.0), 90.0, di)
+    spheres[1] = ((-380.0, 300.0, 180.0), 70.0, me)
+    box_oracle.set_legacy(legacy, spheres)
+    try:
+        ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    finally:
+        box_oracle.set_legacy(None, None)
+    plain_ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    got, plain = _render_gpu_legacy(pt, box_scene, legacy, spheres, BOX_CAMERA, W, H, spp, depth)
+    _assert_same(got, ref)
+    _assert_same(plain, plain_ref)
+    assert (ref[0] != plain_ref[0]).mean() > 0.2                                      # it is a different picture
+    assert ref[0].mean() > 3
+
+
+def test_pure_legacy_scene_with_spheres_matches_the_oracle(pt, ob, gpu_device):
+    """No live material at all: lambertian ground, diffuse_light quad, metal / glass / lambertian spheres
+    (a hollow glass sphere via a negative radius).  Accepted without any light-sampled face."""
+    tris = np.zeros(4, pt.capi.TRIANGLE_DTYPE)
+    quad = lambda k, a, b, c, d, m: [  # noqa: E731  (wound so that the geometric normal of the ground points up)
+        (k, a, c, b, m), (k + 1, a, d, c, m)]
+    for k, a, b, c, m in quad(0, (-30, 0, -30), (30, 0, -30), (30, 0, 30), (-30, 0, 30), 0) + \
+            quad(2, (-7, 9, -7), (7, 9, -7), (7, 9, 7), (-7, 9, 7), 1):
+        tris[k]["v0"]["position"] = a; tris[k]["v1"]["position"] = b; tris[k]["v2"]["position"] = c
+        tris[k]["materialIdx"] = m
+    mats = np.zeros(5, pt.capi.MATERIAL_DTYPE)
+    mats["baseColorTextureIdx"] = -1; mats["emissiveTextureIdx"] = -1
+    legacy = _legacy_records(pt, [(1, (0.5, 0.6, 0.4), 0.0), (4, (4.0, 3.7, 3.4), 0.0), (2, (0.9, 0.7, 0.3), 0.0),
+                                  (3, (0, 0, 0), 1.5), (1, (0.2, 0.3, 0.8), 0.0)])
+    spheres = np.zeros(4, pt.capi.SPHERE_DTYPE)
+    spheres[0] = ((-3.0, 1.5, 0.0), 1.5, 2)
+    spheres[1] = ((0.5, 1.5, 1.0), 1.5, 3)
+    spheres[2] = ((0.5, 1.5, 1.0), -1.3, 3)
+    spheres[3] = ((3.5, 1.0, -1.0), 1.0, 4)
+    cam = ((0.0, 4.0, 12.0), (0.0, -0.25, -1.0), 40.0, 55.0)
+    W, H, spp, depth = 80, 48, 16, 10
+    scene = pt.HostScene.from_arrays(tris, mats, [])
+    osc = ob.OracleScene(tris, mats, [])
+    osc.set_legacy(legacy, spheres)
+    ref = osc.render(cam, W, H, spp, depth, threads=8)
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    cc = pt.CameraConfig(cam[0], cam[1], cam[2], cam[3])
+    # without the extension this scene has no light-sampled face: refused
+    with pytest.raises(pt.capi.PtError):
+        pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, cc)
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, cc, legacyMaterials=legacy, spheres=spheres)
+    tr.resetCounters()
+    tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+    _assert_same((fb.rgb_host().copy(), fb.yuv_host().copy(), tr.readCounters()), ref)
+    assert ref[0].mean() > 5 and len(np.unique(ref[0].reshape(-1, 3), axis=0)) > 100
+    # the extension needs the reference tree, and the uniform walks are not compiled for it
+    with pytest.raises(pt.capi.PtError):
+        tr.setBvhMode(1)
+    tr.setBvhMode(0)
+    with pytest.raises(pt.capi.PtError):
+        tr.setTraversalMode(2)
+    tr.close()
