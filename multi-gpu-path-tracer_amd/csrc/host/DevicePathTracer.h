@@ -101,6 +101,15 @@ public:
     // opt-in SAH tree instead of the reference's topology (include/pt_amd.h: pt_set_bvh_mode)
     void setBvhMode(int mode) { checkPtErrors(pt_set_bvh_mode(dev_, mode)); reloadWorld(); }
 
+    // EXTENSION (include/pt_amd.h pt_set_legacy_scene): legacy material kinds per material and
+    // spheres; empty vectors switch it off.  Takes effect through reloadWorld().
+    void setLegacyScene(const std::vector<pt_legacy_material> &materials, const std::vector<pt_sphere> &spheres)
+    {
+        checkPtErrors(pt_set_legacy_scene(dev_, materials.empty() ? nullptr : materials.data(), materials.size(),
+                                          spheres.empty() ? nullptr : spheres.data(), spheres.size()));
+        reloadWorld();
+    }
+
     // tiles in raster order (0) or ordered by their cost in the previous launch of the same task (1, default)
     void setTileSchedule(int mode) { checkPtErrors(pt_set_tile_schedule(dev_, mode)); }
 
