@@ -122,6 +122,15 @@ typedef struct pt_sphere { float center[3]; float radius; int materialIdx; } pt_
 PT_API pt_status pt_set_legacy_scene(pt_device *dev, const pt_legacy_material *materials, size_t n_materials,
                                      const pt_sphere *spheres, size_t n_spheres);
 
+/* Cooperative tiles, for reference trees with big leaves walked by the wave-uniform stack walk (the duck:
+ * one leaf of 1603 triangles): the four waves of a workgroup render the SAME 8x8 tile, each testing a
+ * quarter of every leaf's triangles, and merge their closest hits once per ray segment (min over t, ties
+ * by the reference's visit order).  Image and counters are unchanged; a tile's sequential chain gets ~3.5x
+ * shorter for more total work, which pays when the launch is small for the GPU (a rank's share of a
+ * multi-GPU frame).  -1 (default): automatic (leaf >= 64 triangles and tiles * 4 <= 3 x the device's wave
+ * slots); 0: never; 1: whenever that walk is in use.                                              */
+PT_API pt_status pt_set_cooperative_mode(pt_device *dev, int mode);
+
 /* Order in which a launch hands its 8x8-pixel tiles to waves.  0: raster order.  1 (default):
  * cost order -- every launch records what each tile cost (shader-clock ticks) and a device radix
  * sort makes that the next launch's order for the same task rectangle / band set, dearest tiles

@@ -97,6 +97,7 @@ _PROTOS = {
     "pt_fb_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "pt_fb_download_task": (C.c_int, [_vp, C.POINTER(Task), _vp, _vp, _vp]),
     "pt_set_tile_schedule": (C.c_int, [_vp, C.c_int]),
+    "pt_set_cooperative_mode": (C.c_int, [_vp, C.c_int]),
     "pt_set_legacy_scene": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
     "pt_kat_arith": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t]),
     "pt_kat_exhaustive": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint64, _vp, _vp, C.c_int]),

@@ -110,6 +110,9 @@ public:
         reloadWorld();
     }
 
+    // four waves per tile sharing every leaf's triangles: -1 automatic (default), 0 off, 1 on
+    void setCooperativeMode(int mode) { checkPtErrors(pt_set_cooperative_mode(dev_, mode)); }
+
     // tiles in raster order (0) or ordered by their cost in the previous launch of the same task (1, default)
     void setTileSchedule(int mode) { checkPtErrors(pt_set_tile_schedule(dev_, mode)); }
 

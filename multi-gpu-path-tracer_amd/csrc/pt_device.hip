@@ -105,6 +105,75 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
     record_tile_cost(P, tid, wave_max(L.n_seg));      // trips of this wave's loop = segments of its busiest lane
 }
 
+// Cooperative kernel for reference trees with big leaves (cornell_duck: one leaf of 1603 triangles, 2 120
+// triangle tests per ray segment).  The four waves of a workgroup render the SAME 8x8 tile: each holds
+// the full path state of its 64 pixels and does the box walk and the shading redundantly (bit-identical,
+// so they never diverge from one another), but tests only its quarter of every leaf's triangles; the
+// four partial closest hits are merged through LDS once per ray segment, min over (t, leaf-order slot) =
+// what the in-order `t < ray_t.max` update of the reference computes.  A tile's samples are one
+// sequential chain (a pixel's RNG stream), so this is the only way to put more than one wave on the
+// dearest tiles: the chain gets ~3.5x shorter for ~10 % more work, which is what a small share of the
+// frame (one rank of a multi-GPU run) and the tail of a whole frame are bound by.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDER_WAVES, PT_RENDER_WAVES))) void render_kernel_coop(RenderParams P)
+{
+    extern __shared__ float4 lds_raw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int part = tid / kWave;                                     // which quarter of each leaf this wave tests
+    const int tile = P.tile_order ? (int)P.tile_order[blockIdx.x] : (int)blockIdx.x;
+    int x, y, pixel_index;
+    const bool in_frame = tile_pixel(P, tile, lane, x, y, pixel_index);
+    const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
+    const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
+    uint32_t *stack = LL.stack + tid;
+    float4 *merge = reinterpret_cast<float4 *>(LL.queue);             // kWavesPerBlock x 64 partial hits ...
+    uint32_t *merge_rank = reinterpret_cast<uint32_t *>(merge + kBlock);   // ... and their visit ranks
+
+    PathState L;
+    path_init(L, P, pixel_index);
+    bool alive = in_frame && P.depth > 0;
+    if (in_frame && P.depth == 0) L.n_paths = (uint32_t)P.spp;
+    uint32_t n_box = 0, n_tri = 0;                                    // box tests are counted by wave 0 only
+    // Every wave of the workgroup runs the same number of trips (identical state), so the barriers match.
+    while (__syncthreads_or(alive)) {
+        bool trace = alive;
+        if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
+        Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+        if (trace) {
+            L.n_seg++;
+            h = traverse_uniform_stack<kWavesPerBlock>(P, L.ro, L.rd, 0.001f, 3.402823466e+38f, stack, kBlock, n_box, n_tri, part);
+        }
+        // equal t (a ray through a shared edge) goes to the triangle the reference visits first; that order is
+        // not the slot order (a leaf child is tested before its inner sibling's subtree), so the partial
+        // hits carry the visit rank stored with each triangle
+        uint32_t rank = 0xffffffffu;
+        if (h.slot >= 0) rank = __float_as_uint(reinterpret_cast<const float *>(P.tris)[12 * (size_t)h.slot + 9]);
+        merge[part * kWave + lane] = make_float4(h.t, h.u, h.v, __int_as_float(h.slot));
+        merge_rank[part * kWave + lane] = rank;
+        __syncthreads();
+        if (trace) {
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; w++) {
+                const float4 m = merge[w * kWave + lane];
+                const uint32_t r = merge_rank[w * kWave + lane];
+                const int slot = __float_as_int(m.w);
+                if (slot >= 0 && (h.slot < 0 || m.x < h.t || (m.x == h.t && r < rank))) { h.t = m.x; h.u = m.y; h.v = m.z; h.slot = slot; rank = r; }
+            }
+            shade(L, P, V, h);
+        }
+    }
+    const uint32_t cost = wave_max(L.n_seg);
+    if (part == 0) {
+        if (in_frame) write_pixel(P, L.col, pixel_index);
+        L.n_box = n_box; L.n_tri = n_tri;
+    } else {
+        L.n_paths = L.n_seg = L.n_box = L.n_light = 0;                // counted once, by wave 0
+        L.n_tri = n_tri;
+    }
+    flush_counters(P, L, lane);
+    if (part == 0 && P.tile_cost && lane == 0) P.tile_cost[tile] = cost;
+}
+
 // Render kernel for the SAH tree: same integrator, but the wave does not finish one ray segment
 // per trip.  Path lengths through a deep tree differ by orders of magnitude between the lanes of
 // a wave (a ray skimming the terrain visits hundreds of nodes, its neighbour ten), so the wave
@@ -344,6 +413,8 @@ struct pt_device {
     float4 *d_legacy = nullptr, *d_spheres = nullptr;
     int n_spheres = 0;
     bool legacy_on = false;       // the uploaded scene uses a legacy material or a sphere
+    int coop_mode = -1;           // cooperative kernel: -1 auto (stack walk, big leaf, small launch), 0 off, 1 on
+    int max_waves = 8192;         // wave slots of the device: CUs x 4 SIMDs x 8
     // adaptive tile schedule
     int tile_schedule = 1;        // 0 raster order, 1 cost-ordered from the previous launch of the same task
     std::vector<TileSchedule *> schedules;
@@ -435,6 +506,12 @@ pt_status pt_device_create(int device_index, pt_device **out)
     d->index = device_index;
     if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;      // diagnostic A/B switches
     if (getenv("PTAMD_SPEC_PCT")) d->spec_pct = atoi(getenv("PTAMD_SPEC_PCT"));
+    if (getenv("PTAMD_COOP")) d->coop_mode = atoi(getenv("PTAMD_COOP"));
+    {
+        hipDeviceProp_t prop;
+        PT_HIP(hipGetDeviceProperties(&prop, device_index));
+        d->max_waves = std::max(1, prop.multiProcessorCount) * 4 * 8;
+    }
     PT_HIP(hipMalloc((void **)&d->d_counters, 8 * sizeof(unsigned long long)));
     PT_HIP(hipMemset(d->d_counters, 0, 8 * sizeof(unsigned long long)));
     *out = d.release();
@@ -731,6 +808,14 @@ pt_status pt_set_legacy_scene(pt_device *dev, const pt_legacy_material *material
     return PT_OK;
 }
 
+pt_status pt_set_cooperative_mode(pt_device *dev, int mode)
+{
+    clear_error();
+    if (!dev || mode < -1 || mode > 1) return set_error(PT_ERR_INVALID, "mode must be -1 (auto), 0 (off) or 1 (on)");
+    dev->coop_mode = mode;
+    return PT_OK;
+}
+
 pt_status pt_set_tile_schedule(pt_device *dev, int mode)
 {
     clear_error();
@@ -856,6 +941,14 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     const bool stage = dev->lds_scene && walk == 0 && !dev->legacy_on, packed = dev->packed_queue && !dev->legacy_on;
     if (walk != 0) P.queue_entries = 0;
     if (walk == 1) P.stack_entries = 0;
+    // big leaves + stack walk: four waves per tile, each testing a quarter of every leaf (render_kernel_coop)
+    // It pays when the launch is small for the machine (a rank's share of a multi-GPU frame): measured on
+    // the duck, 1/6 of a 1080p frame and less gains (1/8: 1.85 -> 1.09 s), 1/4 and more loses (whole frame
+    // 5.3 -> 7.1 s) -- the redundant box walks and the two barriers per trip cost throughput.
+    const bool coop = walk == 2 && !dev->legacy_on &&
+                      (dev->coop_mode == 1 || (dev->coop_mode < 0 && dev->bvh.max_leaf >= 64 &&
+                                               tiles * dev::kWavesPerBlock <= 3ll * dev->max_waves));
+    if (coop) { blocks = (unsigned)tiles; P.queue_entries = dev::kWavesPerBlock + 1; P.queue_dwords = 1; }   // LDS: float4 + rank per thread for the merge
     size_t lds = lds_bytes(P, dev::kBlock, stage);
     hipStream_t hs = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev;
@@ -866,7 +959,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         if (!dev->free_events.empty()) { ev = dev->free_events.back(); dev->free_events.pop_back(); }
         else { PT_HIP(hipEventCreate(&ev.first)); PT_HIP(hipEventCreate(&ev.second)); }
         // one wave slot per tile; tiny launches are not worth a sort
-        if (dev->tile_schedule == 1 && blocks >= 64) sched = schedule_for(dev, P, blocks * dev::kWavesPerBlock, hs);
+        if (dev->tile_schedule == 1 && blocks >= 64) sched = schedule_for(dev, P, coop ? blocks : blocks * dev::kWavesPerBlock, hs);
         if (sched) {
             // a schedule is read and rewritten by its launches: order them across streams
             if (sched->used && sched->last_stream != hs) PT_HIP(hipStreamWaitEvent(hs, sched->last_use, 0));
@@ -882,6 +975,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     }
     else if (walk == 3) hipLaunchKernelGGL((dev::render_kernel<false, true, 3>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (walk == 1) hipLaunchKernelGGL((dev::render_kernel<false, true, 1>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    else if (coop) hipLaunchKernelGGL(dev::render_kernel_coop, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (walk == 2) hipLaunchKernelGGL((dev::render_kernel<false, true, 2>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (dev->legacy_on) hipLaunchKernelGGL((dev::render_kernel<false, false, 0, true>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     else if (stage && packed) hipLaunchKernelGGL((dev::render_kernel<true, true, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);

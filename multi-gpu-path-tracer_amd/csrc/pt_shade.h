@@ -416,7 +416,7 @@ __device__ __forceinline__ void flush_counters(const RenderParams &P, const Path
 {
     uint32_t c0 = wave_sum(L.n_paths), c1 = wave_sum(L.n_seg), c2 = wave_sum(L.n_box), c3 = wave_sum(L.n_tri),
              c4 = wave_sum(L.n_light);
-    if (lane == 0 && (c0 | c1)) {
+    if (lane == 0 && (c0 | c1 | c2 | c3 | c4)) {
         atomicAdd(&P.counters[0], (unsigned long long)c0);
         atomicAdd(&P.counters[1], (unsigned long long)c1);
         atomicAdd(&P.counters[2], (unsigned long long)c2);
@@ -449,10 +449,15 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 // Pixel of this lane: 8x8 tile per wave; in row-band mode (pt_render_bands_async) local row j is row
 // (j % band_rows) of this rank's (j / band_rows)-th band, band b of the frame (fb rows, 0 = top)
 // belonging to rank b % band_ranks.
+__device__ __forceinline__ bool tile_pixel(const RenderParams &P, int tile, int lane, int &x, int &y, int &pixel_index);
+
 __device__ __forceinline__ bool lane_pixel(const RenderParams &P, int tid, int &x, int &y, int &pixel_index)
 {
-    const int lane = tid & (kWave - 1);
-    const int tile = wave_tile(P, tid);
+    return tile_pixel(P, wave_tile(P, tid), tid & (kWave - 1), x, y, pixel_index);
+}
+
+__device__ __forceinline__ bool tile_pixel(const RenderParams &P, int tile, int lane, int &x, int &y, int &pixel_index)
+{
     const int tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
     const int i = tile_x * 8 + (lane & 7), j = tile_y * 8 + (lane >> 3);
     const bool in_task = (tile_y < P.tiles_y) && (i < P.task_w) && (j < P.task_h);

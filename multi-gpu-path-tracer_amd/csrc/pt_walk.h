@@ -257,8 +257,13 @@ __device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 
 // their box, with triangle records coming through the scalar cache -- a 1603-triangle leaf costs
 // 1603 uniform trips instead of 1603 divergent gather trips per lane.  Cost per ray segment is
 // the UNION of the lanes' paths, so the host picks this walk only for small / medium trees.
+// kParts > 1 (cooperative kernel): the kParts waves of a workgroup walk the SAME 64 rays; every wave does
+// the whole box walk (aabb::hit ignores ray_t, so the walk does not depend on triangle results) but tests
+// only its contiguous share of each leaf's triangles.  The caller merges the kParts partial closest hits.
+template <int kParts = 1>
 __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
-                                                      uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
+                                                      uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri,
+                                                      int part = 0)
 {
     Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
     float tmax = tmax0;
@@ -301,7 +306,13 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
             const bool hit = side ? hr : hl;
             const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
             if (cnt != 0 && __ballot(hit) != 0ull) {
-                for (uint32_t k = link; k < link + cnt; k++) {
+                uint32_t k0 = link, k1 = link + cnt;
+                if (kParts > 1) {
+                    const uint32_t share = (cnt + kParts - 1) / kParts;
+                    k0 = link + (uint32_t)part * share;
+                    k1 = k0 + share < link + cnt ? k0 + share : link + cnt;
+                }
+                for (uint32_t k = k0; k < k1; k++) {
                     const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
                     const float e2z = tris.scalar(3 * k + 2, 0);
                     if (hit) {

@@ -307,6 +307,10 @@ class DevicePathTracer:
         if reload:
             self.reloadWorld()
 
+    def setCooperativeMode(self, mode: int):
+        """-1 automatic (default), 0 off, 1 on: four waves per tile sharing each leaf's triangles (big-leaf trees)."""
+        capi.check(capi.lib().pt_set_cooperative_mode(self._h, mode))
+
     def setTileSchedule(self, mode: int):
         """0 raster order, 1 (default) tiles ordered by their cost in the previous launch of the same task."""
         capi.check(capi.lib().pt_set_tile_schedule(self._h, mode))

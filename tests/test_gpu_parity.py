@@ -12,11 +12,12 @@ from conftest import BOX_CAMERA, DUCK_CAMERA
 pytestmark = pytest.mark.gpu
 
 
-def _render_gpu(pt, scene, camera, W, H, spp, depth, tasks=None, device=0, mode=0):
+def _render_gpu(pt, scene, camera, W, H, spp, depth, tasks=None, device=0, mode=0, coop=-1):
     cam = pt.CameraConfig(camera[0], camera[1], camera[2], camera[3])
     fb = pt.Framebuffer(pt.Resolution(W, H), device="cuda:%d" % device)
     tracer = pt.DevicePathTracer(device, spp, depth, (8, 8), scene, fb, cam)
     tracer.setTraversalMode(mode)
+    tracer.setCooperativeMode(coop)
     tracer.resetCounters()
     for t in (tasks or [pt.RenderTask(W, H, 0, 0)]):
         tracer.renderTaskAsync(t)
@@ -149,11 +150,14 @@ def test_cornell_box_config1_400x400_16spp_4bounce(pt, box_scene, box_oracle, gp
     _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, 400, 400, 16, 4), ref)
 
 
-@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("mode,coop", [(1, -1), (3, 0), (3, 1)])
 @pytest.mark.parametrize("W,H,spp,depth", [(64, 36, 2, 4), (96, 54, 3, 8)])
-def test_cornell_duck_image_bit_exact(pt, duck_scene, duck_oracle, gpu_device, W, H, spp, depth, mode):
+def test_cornell_duck_image_bit_exact(pt, duck_scene, duck_oracle, gpu_device, W, H, spp, depth, mode, coop):
+    """Per-lane walk, wave-uniform stack walk with one wave per tile, and the cooperative kernel (four
+    waves per tile, each testing a quarter of every leaf, closest hits merged by the reference's visit
+    order): bytes and all counters equal the oracle's."""
     ref = duck_oracle.render(DUCK_CAMERA, W, H, spp, depth, threads=8)
-    _assert_same(_render_gpu(pt, duck_scene, DUCK_CAMERA, W, H, spp, depth, mode=mode), ref)
+    _assert_same(_render_gpu(pt, duck_scene, DUCK_CAMERA, W, H, spp, depth, mode=mode, coop=coop), ref)
 
 
 def test_task_partition_invariance(pt, box_scene, box_oracle, gpu_device):
@@ -316,7 +320,8 @@ def test_random_scenes_bit_exact_in_every_walk(pt, ob, gpu_device, seed):
     info = pt.host_bvh_build(tris)[0]
     modes = [1, 3] + ([2] if info["nodes"] - info["leaves"] <= 64 else [])
     for mode in modes:
-        _assert_same(_render_gpu(pt, scene, cam, W, H, spp, depth, mode=mode), ref)
+        _assert_same(_render_gpu(pt, scene, cam, W, H, spp, depth, mode=mode, coop=0), ref)
+    _assert_same(_render_gpu(pt, scene, cam, W, H, spp, depth, mode=3, coop=1), ref)      # cooperative tiles, small leaves too
 
 
 # ---- extension: legacy material classes + spheres (pt_set_legacy_scene) -----------------
