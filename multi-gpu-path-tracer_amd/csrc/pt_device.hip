@@ -948,7 +948,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     const bool coop = walk == 2 && !dev->legacy_on &&
                       (dev->coop_mode == 1 || (dev->coop_mode < 0 && dev->bvh.max_leaf >= 64 &&
                                                tiles * dev::kWavesPerBlock <= 3ll * dev->max_waves));
-    if (coop) { blocks = (unsigned)tiles; P.queue_entries = dev::kWavesPerBlock + 1; P.queue_dwords = 1; }   // LDS: float4 + rank per thread for the merge
+    if (coop) { blocks = (unsigned)tiles; P.queue_entries = 5; P.queue_dwords = 1; }   // LDS per thread: one float4 partial hit + its visit rank
     size_t lds = lds_bytes(P, dev::kBlock, stage);
     hipStream_t hs = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev;
