@@ -126,16 +126,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
     const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
     const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
     uint32_t *stack = LL.stack + tid;
-    float4 *merge = reinterpret_cast<float4 *>(LL.queue);             // kWavesPerBlock x 64 partial hits ...
-    uint32_t *merge_rank = reinterpret_cast<uint32_t *>(merge + kBlock);   // ... and their visit ranks
+    // two merge buffers of {float4 partial hit, visit rank} per thread, used alternately: one barrier per trip
+    float4 *merge = reinterpret_cast<float4 *>(LL.queue);
+    uint32_t *merge_rank = reinterpret_cast<uint32_t *>(merge + 2 * kBlock);
 
     PathState L;
     path_init(L, P, pixel_index);
     bool alive = in_frame && P.depth > 0;
     if (in_frame && P.depth == 0) L.n_paths = (uint32_t)P.spp;
     uint32_t n_box = 0, n_tri = 0;                                    // box tests are counted by wave 0 only
-    // Every wave of the workgroup runs the same number of trips (identical state), so the barriers match.
-    while (__syncthreads_or(alive)) {
+    // The four waves hold bit-identical state, so they run the same number of trips and meet at one barrier
+    // per trip; trip n+1 writes the other buffer, and by the time buffer n is written again (trip n+2) every
+    // wave has passed the barrier of trip n+1, i.e. has finished reading it.
+    int buf = 0;
+    while (__any(alive)) {
         bool trace = alive;
         if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
         Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
@@ -148,19 +152,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
         // hits carry the visit rank stored with each triangle
         uint32_t rank = 0xffffffffu;
         if (h.slot >= 0) rank = __float_as_uint(reinterpret_cast<const float *>(P.tris)[12 * (size_t)h.slot + 9]);
-        merge[part * kWave + lane] = make_float4(h.t, h.u, h.v, __int_as_float(h.slot));
-        merge_rank[part * kWave + lane] = rank;
+        merge[buf * kBlock + tid] = make_float4(h.t, h.u, h.v, __int_as_float(h.slot));
+        merge_rank[buf * kBlock + tid] = rank;
         __syncthreads();
         if (trace) {
 #pragma unroll
             for (int w = 0; w < kWavesPerBlock; w++) {
-                const float4 m = merge[w * kWave + lane];
-                const uint32_t r = merge_rank[w * kWave + lane];
+                const float4 m = merge[buf * kBlock + w * kWave + lane];
+                const uint32_t r = merge_rank[buf * kBlock + w * kWave + lane];
                 const int slot = __float_as_int(m.w);
                 if (slot >= 0 && (h.slot < 0 || m.x < h.t || (m.x == h.t && r < rank))) { h.t = m.x; h.u = m.y; h.v = m.z; h.slot = slot; rank = r; }
             }
             shade(L, P, V, h);
         }
+        buf ^= 1;
     }
     const uint32_t cost = wave_max(L.n_seg);
     if (part == 0) {
@@ -948,7 +953,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     const bool coop = walk == 2 && !dev->legacy_on &&
                       (dev->coop_mode == 1 || (dev->coop_mode < 0 && dev->bvh.max_leaf >= 64 &&
                                                tiles * dev::kWavesPerBlock <= 3ll * dev->max_waves));
-    if (coop) { blocks = (unsigned)tiles; P.queue_entries = 5; P.queue_dwords = 1; }   // LDS per thread: one float4 partial hit + its visit rank
+    if (coop) { blocks = (unsigned)tiles; P.queue_entries = 10; P.queue_dwords = 1; }   // LDS per thread: 2 x (float4 partial hit + visit rank)
     size_t lds = lds_bytes(P, dev::kBlock, stage);
     hipStream_t hs = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev;
