@@ -143,15 +143,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
         bool trace = alive;
         if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
         Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
-        if (trace) {
-            L.n_seg++;
-            h = traverse_uniform_stack<kWavesPerBlock>(P, L.ro, L.rd, 0.001f, 3.402823466e+38f, stack, kBlock, n_box, n_tri, part);
-        }
         // equal t (a ray through a shared edge) goes to the triangle the reference visits first; that order is
         // not the slot order (a leaf child is tested before its inner sibling's subtree), so the partial
         // hits carry the visit rank stored with each triangle
         uint32_t rank = 0xffffffffu;
-        if (h.slot >= 0) rank = __float_as_uint(reinterpret_cast<const float *>(P.tris)[12 * (size_t)h.slot + 9]);
+        if (trace) {
+            L.n_seg++;
+            h = traverse_uniform_stack<kWavesPerBlock>(P, L.ro, L.rd, 0.001f, 3.402823466e+38f, stack, kBlock, n_box, n_tri, part, &rank);
+        }
         merge[buf * kBlock + tid] = make_float4(h.t, h.u, h.v, __int_as_float(h.slot));
         merge_rank[buf * kBlock + tid] = rank;
         __syncthreads();

@@ -263,9 +263,10 @@ __device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 
 template <int kParts = 1>
 __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
                                                       uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri,
-                                                      int part = 0)
+                                                      int part = 0, uint32_t *rank_out = nullptr)
 {
     Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+    uint32_t best_rank = 0xffffffffu;
     float tmax = tmax0;
     const v3 inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
     const ConstF4 nodes = as_constant(P.nodes);
@@ -315,17 +316,20 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
                 for (uint32_t k = k0; k < k1; k++) {
                     const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
                     const float e2z = tris.scalar(3 * k + 2, 0);
+                    const uint32_t krank = kParts > 1 ? __float_as_uint(tris.scalar(3 * k + 2, 1)) : 0u;
                     if (hit) {
                         float t, u, v;
                         n_tri++;
                         if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
                             tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k;
+                            if (kParts > 1) best_rank = krank;
                         }
                     }
                 }
             }
         }
     }
+    if (kParts > 1 && rank_out) *rank_out = best_rank;
     return h;
 }
 
