@@ -252,6 +252,11 @@ PT_API const pt_triangle *pt_scene_triangles(const pt_host_scene *scene);
 PT_API const pt_material *pt_scene_materials(const pt_host_scene *scene);
 PT_API const pt_texture  *pt_scene_textures(const pt_host_scene *scene);
 PT_API const char *pt_scene_material_name(const pt_host_scene *scene, size_t index);
+/* EXTENSION: the legacy class obj_loader.h:65-96 picks for each material by name prefix -- lambertian*
+ * (albedo = Ka), metal* (albedo = Ka, fuzz = Ns), dielectric* (ir = Ni), diffuse_light* (color = Kd) -- as
+ * records for pt_set_legacy_scene; kind 0 for every other name and for glTF input.  Returns the number of
+ * materials and copies at most `cap` records.                                                       */
+PT_API size_t    pt_scene_legacy_materials(const pt_host_scene *scene, pt_legacy_material *out, size_t cap);
 /* Benchmark convention for models/cornell_box.glb (BASELINE.md note 1):
  * (i) zero-emissive materials named diffuse_light* get emissiveFactor (1,1,1);
  * (ii) exact axis swap (x,y,z) -> (x,z,-y) on every vertex.                             */

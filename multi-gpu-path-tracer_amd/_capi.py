@@ -99,6 +99,7 @@ _PROTOS = {
     "pt_set_tile_schedule": (C.c_int, [_vp, C.c_int]),
     "pt_set_cooperative_mode": (C.c_int, [_vp, C.c_int]),
     "pt_set_legacy_scene": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),
+    "pt_scene_legacy_materials": (C.c_size_t, [_vp, _vp, C.c_size_t]),
     "pt_kat_arith": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t]),
     "pt_kat_exhaustive": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint64, _vp, _vp, C.c_int]),
     "pt_kat_closest_hit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_size_t]),

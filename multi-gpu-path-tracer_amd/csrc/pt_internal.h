@@ -21,6 +21,9 @@ struct HostSceneImpl {
     std::vector<std::string> material_names;
     std::vector<std::vector<float>> texel_storage;   // float3 texels per texture
     std::vector<pt_texture> textures;                // views into texel_storage
+    // what obj_loader.h:65-96 would have made of each material name (lambertian* / metal* / dielectric* /
+    // diffuse_light*): records for the pt_set_legacy_scene extension; kind 0 for every other name
+    std::vector<pt_legacy_material> legacy;
     void rebuild_texture_views();
 };
 } // namespace pt

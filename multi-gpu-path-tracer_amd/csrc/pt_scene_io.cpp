@@ -761,7 +761,7 @@ static pt_status load_obj_impl(const char *path, HostSceneImpl &scene)
 {
     std::ifstream f(path);
     if (!f) return set_error(PT_ERR_IO, std::string("cannot open ") + path);
-    struct Mtl { float ka[3] = {1, 1, 1}, kd[3] = {1, 1, 1}, ke[3] = {0, 0, 0}; };
+    struct Mtl { float ka[3] = {1, 1, 1}, kd[3] = {1, 1, 1}, ke[3] = {0, 0, 0}; float ns = 0.0f, ni = 1.0f; };
     std::map<std::string, Mtl> mtls;
     std::map<std::string, int> mat_index;
     std::vector<float> pos, uv;
@@ -775,9 +775,19 @@ static pt_status load_obj_impl(const char *path, HostSceneImpl &scene)
         for (int k = 0; k < 3; k++) { pm.baseColor[k] = m.kd[k]; pm.emissiveFactor[k] = m.ke[k]; }
         if (name.rfind("lambertian", 0) == 0) for (int k = 0; k < 3; k++) pm.baseColor[k] = m.ka[k];
         if (name.rfind("diffuse_light", 0) == 0) for (int k = 0; k < 3; k++) { pm.emissiveFactor[k] = m.kd[k]; pm.baseColor[k] = 0.0f; }
+        // the legacy class obj_loader.h:65-96 picks by name prefix: lambertian(Ka), metal(Ka, shininess Ns),
+        // dielectric(Ni), diffuse_light(Kd) -- offered to pt_set_legacy_scene, ignored by the live path
+        pt_legacy_material lm;
+        memset(&lm, 0, sizeof lm);
+        if (name.rfind("lambertian", 0) == 0) { lm.kind = 1; for (int k = 0; k < 3; k++) lm.albedo[k] = m.ka[k]; }
+        else if (name.rfind("metal", 0) == 0) { lm.kind = 2; for (int k = 0; k < 3; k++) lm.albedo[k] = m.ka[k]; lm.param = m.ns; }
+        else if (name.rfind("dielectric", 0) == 0) { lm.kind = 3; lm.param = m.ni; }
+        else if (name.rfind("diffuse_light", 0) == 0) { lm.kind = 4; for (int k = 0; k < 3; k++) lm.albedo[k] = m.kd[k]; }
         int idx = (int)scene.materials.size();
         scene.materials.push_back(pm);
         scene.material_names.push_back(name);
+        scene.legacy.resize(scene.materials.size());
+        scene.legacy[(size_t)idx] = lm;
         mat_index[name] = idx;
         return idx;
     };
@@ -839,6 +849,9 @@ static pt_status load_obj_impl(const char *path, HostSceneImpl &scene)
                     curname = ml.substr(7);
                     while (!curname.empty() && (curname.back() == '\r' || curname.back() == ' ')) curname.pop_back();
                     mtls[curname] = Mtl();
+                } else if (!curname.empty() && ml.size() > 3 && ml[0] == 'N' && (ml[1] == 's' || ml[1] == 'i') && ml[2] == ' ') {
+                    float v;
+                    if (sscanf(ml.c_str() + 3, "%f", &v) == 1) (ml[1] == 's' ? mtls[curname].ns : mtls[curname].ni) = v;
                 } else if (!curname.empty() && ml.size() > 3 && ml[0] == 'K') {
                     float a, b, c;
                     if (sscanf(ml.c_str() + 3, "%f %f %f", &a, &b, &c) == 3) {
@@ -871,6 +884,19 @@ pt_status pt_scene_load_glb(const char *path, pt_host_scene **out)
     if (st != PT_OK) return st;
     *out = s.release();
     return PT_OK;
+}
+
+/* Legacy-class records derived from the material names of a loaded scene (OBJ + MTL only; all kind 0 for
+ * glTF input).  Returns the number of materials; copies up to `cap` records. */
+size_t pt_scene_legacy_materials(const pt_host_scene *scene, pt_legacy_material *out, size_t cap)
+{
+    if (!scene) return 0;
+    const HostSceneImpl &s = scene->impl;
+    for (size_t i = 0; out && i < s.materials.size() && i < cap; i++) {
+        if (i < s.legacy.size()) out[i] = s.legacy[i];
+        else memset(&out[i], 0, sizeof out[i]);
+    }
+    return s.materials.size();
 }
 
 pt_status pt_scene_load_obj(const char *path, pt_host_scene **out)

@@ -36,6 +36,14 @@ class HostScene:
         except Exception:
             pass
 
+    def legacyMaterials(self) -> np.ndarray:
+        """EXTENSION: LEGACY_MATERIAL_DTYPE records that obj_loader.h:65-96's name-prefix rule gives this scene's
+        materials (OBJ + MTL input; all kind 0 otherwise), ready for DevicePathTracer.setLegacyScene."""
+        n = capi.lib().pt_scene_legacy_materials(self._h, None, 0)
+        out = np.zeros(n, capi.LEGACY_MATERIAL_DTYPE)
+        capi.lib().pt_scene_legacy_materials(self._h, capi.np_ptr(out), n)
+        return out
+
     @staticmethod
     def from_arrays(triangles: np.ndarray, materials: np.ndarray, textures: Optional[List[np.ndarray]] = None):
         tris = np.ascontiguousarray(triangles, dtype=capi.TRIANGLE_DTYPE)

@@ -194,8 +194,19 @@ def test_ppm_obj_and_terrain(pt, tmp_path):
     assert len(sc.triangles) == 3 and sc.material_names == ["lambertian_grey", "diffuse_light_top"]
     assert np.allclose(sc.materials["baseColor"][0], [0.3, 0.4, 0.5]) and sc.materials["emissiveFactor"][1].tolist() == [2, 2, 2]
     assert sc.triangles["v2"]["texCoords"][1].tolist() == [0, 1]
+    # extension: the legacy class each name would have got from obj_loader.h:65-96
+    (tmp_path / "n.mtl").write_text("newmtl lambertian_a\nKa 0.3 0.4 0.5\nnewmtl metal_b\nKa 0.9 0.8 0.7\nNs 0.25\n"
+                                    "newmtl dielectric_c\nNi 1.5\nnewmtl diffuse_light_d\nKd 4 5 6\nnewmtl other\nKd 0.1 0.2 0.3\n")
+    (tmp_path / "n.obj").write_text("mtllib n.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\n" +
+                                    "".join("usemtl %s\nf 1 2 3\n" % m for m in ("lambertian_a", "metal_b", "dielectric_c", "diffuse_light_d", "other")))
+    lm = pt.SceneLoader().load(str(tmp_path / "n.obj")).legacyMaterials()
+    assert lm["kind"].tolist() == [1, 2, 3, 4, 0]
+    assert np.allclose(lm["albedo"][0], [0.3, 0.4, 0.5]) and np.allclose(lm["albedo"][1], [0.9, 0.8, 0.7]) and np.allclose(lm["albedo"][3], [4, 5, 6])
+    assert np.isclose(lm["param"][1], 0.25) and np.isclose(lm["param"][2], 1.5)
+    assert sc.legacyMaterials()["kind"].tolist() == [1, 4]
     terr = pt.make_terrain_scene(16)
     assert len(terr.triangles) == 2 * 16 * 16 + 2 and np.allclose(terr.materials["emissiveFactor"][1], 0.25)
+    assert not terr.legacyMaterials()["kind"].any()
     t2 = pt.make_terrain_scene(16)
     assert terr.triangles.tobytes() == t2.triangles.tobytes()        # deterministic
     info, _, links, _ = pt.host_bvh_build(terr.triangles)
