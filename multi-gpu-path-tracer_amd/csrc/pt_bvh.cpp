@@ -193,6 +193,14 @@ struct SahNode {
     uint32_t first = 0, count = 0;  // leaf range in the ordered triangle array
 };
 
+// Bin of a scaled centroid offset; non-finite coordinates (inf - inf, NaN from a broken file) land in bin 0
+// instead of indexing out of range.
+static inline int sah_bin(float scaled, int bins)
+{
+    if (!(scaled >= 0.0f)) return 0;
+    return scaled < (float)bins ? (int)scaled : bins - 1;
+}
+
 struct SahBuilder {
     std::vector<SahTri> &tris;
     std::vector<SahNode> nodes;     // per-subtree pools are merged by the caller
@@ -229,7 +237,7 @@ struct SahBuilder {
             for (int b = 0; b < kBins; b++) for (int k = 0; k < 3; k++) { bmn[b][k] = FLT_MAX; bmx[b][k] = -FLT_MAX; }
             float scale = (float)kBins / ext;
             for (uint32_t i = lo; i < hi; i++) {
-                int b = std::min(kBins - 1, (int)((tris[i].c[axis] - cmn[axis]) * scale));
+                int b = sah_bin((tris[i].c[axis] - cmn[axis]) * scale, kBins);
                 cnt[b]++;
                 grow(bmn[b], bmx[b], tris[i].bmin, tris[i].bmax);
             }
@@ -260,7 +268,7 @@ struct SahBuilder {
             float ext = cmx[best_axis] - cmn[best_axis], scale = (float)kBins / ext, base = cmn[best_axis];
             int axis = best_axis, bin = best_bin;
             auto it = std::partition(tris.begin() + lo, tris.begin() + hi, [&](const SahTri &t) {
-                return std::min(kBins - 1, (int)((t.c[axis] - base) * scale)) <= bin;
+                return sah_bin((t.c[axis] - base) * scale, kBins) <= bin;
             });
             mid = (uint32_t)(it - tris.begin());
             if (mid == lo || mid == hi) mid = lo + n / 2;
