@@ -3,7 +3,9 @@
 Random triangle soups (tests/test_gpu_parity.py::_random_scene), random even frame sizes, spp, depth,
 walk schedule, tile schedule, and a random way of covering the frame: one task, a grid of rectangular
 tasks with ragged edges, or single-launch row bands of a random number of ranks.
-usage: python tools/fuzz_parity.py [first_seed] [count]"""
+--legacy adds random legacy material kinds and spheres (the pt_set_legacy_scene extension) to half the cases,
+--sah also renders every case with the SAH tree and reports how many images differ (a statistic, not a gate).
+usage: python tools/fuzz_parity.py [first_seed] [count] [--legacy] [--sah]"""
 import importlib
 import os
 import sys
@@ -19,6 +21,9 @@ from oracle import binding as ob  # noqa: E402  (test infrastructure: this is a 
 import test_gpu_parity as tgp  # noqa: E402
 
 
+LEGACY = "--legacy" in sys.argv
+if LEGACY:
+    sys.argv.remove("--legacy")
 SAH_STATS = {"cases": 0, "cases_differ": 0, "bytes": 0, "bytes_differ": 0} if "--sah" in sys.argv else None
 if SAH_STATS is not None:
     sys.argv.remove("--sah")
@@ -30,12 +35,29 @@ def one(seed):
     W, H = 2 * int(rng.integers(4, 49)), 2 * int(rng.integers(4, 33))
     spp, depth = int(rng.integers(1, 7)), int(rng.integers(0, 10))
     scene = pt.HostScene.from_arrays(tris, mats, texs)
-    ref = ob.OracleScene(tris, mats, texs).render(cam, W, H, spp, depth, threads=8)
+    osc = ob.OracleScene(tris, mats, texs)
+    legacy = spheres = None
+    if LEGACY and rng.random() < 0.5:
+        # extension: random legacy kinds on the non-emissive materials, a few random spheres
+        legacy = np.zeros(len(mats), pt.capi.LEGACY_MATERIAL_DTYPE)
+        for i in range(len(mats)):
+            if mats["emissiveFactor"][i].max() > 0:
+                continue
+            legacy[i]["kind"] = int(rng.integers(0, 5))
+            legacy[i]["albedo"] = rng.uniform(0.05, 1.0, 3) * (4.0 if legacy[i]["kind"] == 4 else 1.0)
+            legacy[i]["param"] = float(rng.choice([0.0, 0.3, 1.7, 1.5, 1.0, 0.6]))
+        spheres = np.zeros(int(rng.integers(0, 4)), pt.capi.SPHERE_DTYPE)
+        for sp in spheres:
+            sp["center"] = rng.uniform(-8, 8, 3); sp["radius"] = float(rng.choice([-1, 1])) * float(rng.uniform(0.3, 4.0))
+            sp["materialIdx"] = int(rng.integers(0, len(mats)))
+        osc.set_legacy(legacy, spheres)
+    ref = osc.render(cam, W, H, spp, depth, threads=8)
     info = pt.host_bvh_build(tris)[0]
     modes = [0, 1, 3] + ([2] if info["nodes"] - info["leaves"] <= 64 else [])
-    mode = int(rng.choice(modes))
+    mode = 0 if legacy is not None else int(rng.choice(modes))
     fb = pt.Framebuffer(pt.Resolution(W, H))
-    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, pt.CameraConfig(cam[0], cam[1], cam[2], cam[3]))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, pt.CameraConfig(cam[0], cam[1], cam[2], cam[3]),
+                             legacyMaterials=legacy, spheres=spheres)
     tr.setTraversalMode(mode)
     tr.setTileSchedule(int(rng.integers(0, 2)))
     cover = int(rng.integers(0, 3))
@@ -60,7 +82,7 @@ def one(seed):
         tgp._assert_same(got, ref)
     tr.close()
     # statistic, not a gate: the opt-in SAH tree is not the reference's traversal
-    if SAH_STATS is not None:
+    if SAH_STATS is not None and legacy is None:
         fb2 = pt.Framebuffer(pt.Resolution(W, H))
         tr2 = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb2, pt.CameraConfig(cam[0], cam[1], cam[2], cam[3]))
         tr2.setBvhMode(1)
