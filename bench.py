@@ -96,8 +96,9 @@ ROOFLINE_NOTES = {
           "the HBM traffic of a launch is `traffic` bytes, the kernel is VALU-issue bound (DESIGN.md 4)",
     "c3": "algorithmic bytes (SURVEY 8d) are served by L1/L2 (0.7 MB of tree + 3 MB texture); the HBM traffic of "
           "a launch is `traffic` bytes; the SAH kernel is issue/divergence bound (DESIGN.md 4)",
-    "c4": "1 GB scene: `traffic` (PMC) is what reaches HBM after L2 + Infinity Cache; the SAH kernel is "
-          "memory-latency bound here (one dependent node or triangle fetch per micro-step, DESIGN.md 4)",
+    "c4": "1 GB scene: `traffic` (PMC FETCH_SIZE x2 + WRITE_SIZE) is what leaves the L2s (Infinity-Cache hits are "
+          "counted in it, MI355X_MICROARCH.md); the SAH kernel is memory-latency bound here (one dependent node or "
+          "triangle fetch per micro-step, DESIGN.md 4)",
 }
 ROOFLINE_NOTES["c1"] = ROOFLINE_NOTES["c5"] = ROOFLINE_NOTES["c2"]
 
