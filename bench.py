@@ -78,9 +78,16 @@ def cpu_baseline(scene, camera, W, H, spp, depth, budget_rows):
     from oracle import binding as ob
     cores = min(os.cpu_count() or 1, 16)
     osc = ob.OracleScene(scene.triangles, scene.materials, scene.textures)
-    rows = max(cores, min(H, budget_rows))
-    oy = (H - rows) // 2
     cam = (camera[0], camera[1], 45.0, 45.0)
+    # size the strip by a probe (an eighth-width patch at the centre) so that the sample stays near 15 s
+    # whatever the scene costs per pixel; never more than budget_rows
+    pw = max(W // 8, 1)
+    t0 = time.perf_counter()
+    osc.render(cam, W, H, spp, depth, task=(pw, cores, (W - pw) // 2, (H - cores) // 2), threads=cores)
+    per_row = (time.perf_counter() - t0) * W / pw / cores
+    rows = int(15.0 / max(per_row, 1e-9)) // cores * cores
+    rows = max(cores, min(H, budget_rows, rows))
+    oy = (H - rows) // 2
     t0 = time.perf_counter()
     _, _, cnt = osc.render(cam, W, H, spp, depth, task=(W, rows, 0, oy), threads=cores)
     dt = time.perf_counter() - t0

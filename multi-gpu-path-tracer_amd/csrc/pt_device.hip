@@ -65,6 +65,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
     const unsigned long long stamp_begin = __builtin_amdgcn_s_memtime();
 #endif
 
+    unsigned long long wave_box = 0, wave_tri = 0;   // wave totals of the wave-uniform walks (kWalk 1, 2)
     while (alive) {
         if (L.need_new && !start_path(L, P, x, y)) { alive = false; continue; }
         L.n_seg++;
@@ -72,8 +73,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
         const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
         Hit h;
-        if (kWalk == 1) h = traverse_uniform(P, L.ro, L.rd, 0.001f, 3.402823466e+38f, L.n_box, L.n_tri);
-        else if (kWalk == 2) h = traverse_uniform_stack(P, L.ro, L.rd, 0.001f, 3.402823466e+38f, stack, kBlock, L.n_box, L.n_tri);
+        if (kWalk == 1) h = traverse_uniform(P, L.ro, L.rd, 0.001f, 3.402823466e+38f, wave_box, wave_tri);
+        else if (kWalk == 2) h = traverse_uniform_stack(P, L.ro, L.rd, 0.001f, 3.402823466e+38f, stack, kBlock, wave_box, wave_tri);
         else if (kWalk == 3) h = traverse_sah(P, L.ro, L.rd, 0.001f, 3.402823466e+38f, stack, kBlock, L.n_box, L.n_tri);
         else h = traverse<kLds, kPacked>(S, L.ro, L.rd, 0.001f, 3.402823466e+38f, stack, queue, kBlock, P.queue_entries, L.n_box, L.n_tri);
 #ifdef PT_STAMPS
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
         }
     }
 #endif
-    flush_counters(P, L, lane);
+    flush_counters(P, L, lane, wave_box, wave_tri);
     record_tile_cost(P, tid, wave_max(L.n_seg));      // trips of this wave's loop = segments of its busiest lane
 }
 
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
     path_init(L, P, pixel_index);
     bool alive = in_frame && P.depth > 0;
     if (in_frame && P.depth == 0) L.n_paths = (uint32_t)P.spp;
-    uint32_t n_box = 0, n_tri = 0;                                    // box tests are counted by wave 0 only
+    unsigned long long n_box = 0, n_tri = 0;                          // wave totals; box tests are counted by wave 0 only
     // The four waves hold bit-identical state, so they run the same number of trips and meet at one barrier
     // per trip; trip n+1 writes the other buffer, and by the time buffer n is written again (trip n+2) every
     // wave has passed the barrier of trip n+1, i.e. has finished reading it.
@@ -169,12 +170,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
     const uint32_t cost = wave_max(L.n_seg);
     if (part == 0) {
         if (in_frame) write_pixel(P, L.col, pixel_index);
-        L.n_box = n_box; L.n_tri = n_tri;
     } else {
-        L.n_paths = L.n_seg = L.n_box = L.n_light = 0;                // counted once, by wave 0
-        L.n_tri = n_tri;
+        L.n_paths = L.n_seg = L.n_light = 0;                          // counted once, by wave 0
     }
-    flush_counters(P, L, lane);
+    flush_counters(P, L, lane, part == 0 ? n_box : 0ull, n_tri);
     if (part == 0 && P.tile_cost && lane == 0) P.tile_cost[tile] = cost;
 }
 

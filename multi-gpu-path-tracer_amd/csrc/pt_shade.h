@@ -44,6 +44,19 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+// 64-bit forms for the test counters: 64 lanes x spp x depth x (triangles of a big leaf) passes 2^32
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_max64(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+
 // Dynamic LDS layout of a workgroup: [staged NodePairs][staged TriIsects] (only when the scene
 // is staged) [traversal stacks: stack_entries x blockDim dwords][leaf queues: queue_entries x
 // blockDim uint2].  All sections are 16-byte aligned.
@@ -412,15 +425,18 @@ __device__ __forceinline__ void write_pixel(const RenderParams &P, v3 col, int p
 }
 
 // Exact work counters: one atomic per wave per counter.
-__device__ __forceinline__ void flush_counters(const RenderParams &P, const PathState &L, int lane)
+// wave_box / wave_tri: totals a wave-uniform walk (traverse_uniform, traverse_uniform_stack) kept for the whole
+// wave.  A lane stops adding to its copy when its pixel is done, so the lane that ran longest holds the total.
+__device__ __forceinline__ void flush_counters(const RenderParams &P, const PathState &L, int lane,
+                                               unsigned long long wave_box = 0, unsigned long long wave_tri = 0)
 {
-    uint32_t c0 = wave_sum(L.n_paths), c1 = wave_sum(L.n_seg), c2 = wave_sum(L.n_box), c3 = wave_sum(L.n_tri),
-             c4 = wave_sum(L.n_light);
-    if (lane == 0 && (c0 | c1 | c2 | c3 | c4)) {
+    const uint32_t c0 = wave_sum(L.n_paths), c1 = wave_sum(L.n_seg), c4 = wave_sum(L.n_light);
+    const unsigned long long c2 = wave_sum64(L.n_box) + wave_max64(wave_box), c3 = wave_sum64(L.n_tri) + wave_max64(wave_tri);
+    if (lane == 0 && ((c0 | c1 | c4) != 0 || (c2 | c3) != 0)) {
         atomicAdd(&P.counters[0], (unsigned long long)c0);
         atomicAdd(&P.counters[1], (unsigned long long)c1);
-        atomicAdd(&P.counters[2], (unsigned long long)c2);
-        atomicAdd(&P.counters[3], (unsigned long long)c3);
+        atomicAdd(&P.counters[2], c2);
+        atomicAdd(&P.counters[3], c3);
         atomicAdd(&P.counters[4], (unsigned long long)c4);
     }
 }

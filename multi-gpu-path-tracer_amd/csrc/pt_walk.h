@@ -206,8 +206,10 @@ __device__ __forceinline__ Hit traverse(const SceneView<kLds> S, v3 o, v3 d, flo
 // (s_load) and sit in SGPRs as instruction operands: no LDS, no per-lane queue, no divergent
 // loop trip counts.  A pair (or a leaf) that no lane of the wave reaches is skipped with one
 // scalar branch.  Per lane the sequence of slab and triangle tests is exactly bvh.h:178-246.
+// n_box / n_tri are WAVE totals here (every lane ends up with the same value, kept in SGPRs): tests are
+// counted as popcount(participating lanes) once per pair / leaf instead of one VALU add per lane and test.
 __device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
-                                                uint32_t &n_box, uint32_t &n_tri)
+                                                unsigned long long &n_box, unsigned long long &n_tri)
 {
     Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
     float tmax = tmax0;
@@ -218,26 +220,27 @@ __device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 
     const int n_pairs = P.n_pairs;
     for (int p = 0; p < n_pairs; p++) {
         const bool on = (act >> p) & 1ull;
-        if (__ballot(on) == 0ull) continue;              // nobody in the wave visits pair p
+        const unsigned long long on_mask = __ballot(on);
+        if (on_mask == 0ull) continue;                   // nobody in the wave visits pair p
         const float4 a = nodes[4 * p], b = nodes[4 * p + 1], c = nodes[4 * p + 2], lf = nodes[4 * p + 3];
         const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
         const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
         const bool hl = on && box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
         const bool hr = on && box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
-        if (on) n_box += 2;
+        n_box += 2u * (uint32_t)__popcll(on_mask);       // wave-uniform count (see the comment above the function)
 #pragma unroll
         for (int side = 0; side < 2; side++) {
             const bool hit = side ? hr : hl;
             const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
             if (cnt == 0) {                              // inner child: mark its pair
                 if (hit) act |= 1ull << link;
-            } else if (__ballot(hit) != 0ull) {          // leaf child somebody hits
+            } else if (const unsigned long long hit_mask = __ballot(hit)) {   // leaf child somebody hits
+                n_tri += (unsigned long long)cnt * (uint32_t)__popcll(hit_mask);
                 for (uint32_t k = link; k < link + cnt; k++) {
                     const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
                     const float e2z = tris.scalar(3 * k + 2, 0);
                     if (hit) {
                         float t, u, v;
-                        n_tri++;
                         if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
                             tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k;
                         }
@@ -262,7 +265,7 @@ __device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 
 // only its contiguous share of each leaf's triangles.  The caller merges the kParts partial closest hits.
 template <int kParts = 1>
 __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
-                                                      uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri,
+                                                      uint32_t *stack, int stride, unsigned long long &n_box, unsigned long long &n_tri,
                                                       int part = 0, uint32_t *rank_out = nullptr)
 {
     Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
@@ -277,7 +280,8 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
     const int n_pairs = P.n_pairs;
     for (int p = 0; p < n_pairs; p++) {
         const bool on = walking && next == (uint32_t)p;
-        if (__ballot(on) == 0ull) {
+        const unsigned long long on_mask = __ballot(on);
+        if (on_mask == 0ull) {
             if (__ballot(walking) == 0ull) break;        // every lane of the wave is done
             continue;
         }
@@ -286,8 +290,8 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
         const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
         const bool hl = on && box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
         const bool hr = on && box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
+        n_box += 2u * (uint32_t)__popcll(on_mask);       // wave totals, as in traverse_uniform
         if (on) {
-            n_box += 2;
             const bool tl = hl && lcnt == 0, tr = hr && rcnt == 0;
             if (tl && tr) {
                 stack[sp * stride] = rlink;
@@ -306,20 +310,21 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
         for (int side = 0; side < 2; side++) {
             const bool hit = side ? hr : hl;
             const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
-            if (cnt != 0 && __ballot(hit) != 0ull) {
+            const unsigned long long hit_mask = cnt != 0 ? __ballot(hit) : 0ull;
+            if (hit_mask != 0ull) {
                 uint32_t k0 = link, k1 = link + cnt;
                 if (kParts > 1) {
                     const uint32_t share = (cnt + kParts - 1) / kParts;
                     k0 = link + (uint32_t)part * share;
                     k1 = k0 + share < link + cnt ? k0 + share : link + cnt;
                 }
+                if (k1 > k0) n_tri += (unsigned long long)(k1 - k0) * (uint32_t)__popcll(hit_mask);
                 for (uint32_t k = k0; k < k1; k++) {
                     const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
                     const float e2z = tris.scalar(3 * k + 2, 0);
                     const uint32_t krank = kParts > 1 ? __float_as_uint(tris.scalar(3 * k + 2, 1)) : 0u;
                     if (hit) {
                         float t, u, v;
-                        n_tri++;
                         if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
                             tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k;
                             if (kParts > 1) best_rank = krank;
