@@ -48,8 +48,28 @@ struct Json {
     size_t size() const { return kind == Arr ? arr.size() : 0; }
     const Json &at(size_t i) const { return arr[i]; }
     double number(double dflt) const { return kind == Num ? num : dflt; }
-    int integer(int dflt) const { return kind == Num ? (int)num : dflt; }
+    // out-of-range and non-finite numbers are not indices: the default (callers pass an invalid one) stands
+    int integer(int dflt) const { return kind == Num && num >= -2147483648.0 && num <= 2147483647.0 ? (int)num : dflt; }
 };
+
+// A byte offset, length, stride or element count: absent -> dflt; anything but a finite number in [0, 2^48) -> false.
+static bool json_size(const Json *j, size_t dflt, size_t &out)
+{
+    out = dflt;
+    if (!j) return true;
+    if (j->kind != Json::Num || !(j->num >= 0.0 && j->num < 281474976710656.0)) return false;
+    out = (size_t)j->num;
+    return true;
+}
+
+// Do `count` elements of `elem` bytes, `stride` apart, starting at `off`, lie inside `len` bytes?  (No product that
+// can wrap: every operand is below 2^48 but count x stride is not.)
+static bool span_fits(size_t off, size_t count, size_t stride, size_t elem, size_t len)
+{
+    if (count == 0) return off <= len;
+    if (elem > len || off > len - elem) return false;
+    return stride == 0 || count - 1 <= (len - elem - off) / stride;
+}
 
 struct JsonParser {
     const char *p, *end;
@@ -460,10 +480,9 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
         const Json &v = jviews->at((size_t)view);
         int buffer = v.get("buffer") ? v.get("buffer")->integer(0) : 0;
         if (buffer < 0 || (size_t)buffer >= buffers.size() || !buffers[(size_t)buffer].first) return false;
-        size_t off = v.get("byteOffset") ? (size_t)v.get("byteOffset")->number(0) : 0;
-        len = v.get("byteLength") ? (size_t)v.get("byteLength")->number(0) : 0;
-        stride = v.get("byteStride") ? (size_t)v.get("byteStride")->number(0) : 0;
-        if (off + len > buffers[(size_t)buffer].second) return false;
+        size_t off;
+        if (!json_size(v.get("byteOffset"), 0, off) || !json_size(v.get("byteLength"), 0, len) || !json_size(v.get("byteStride"), 0, stride)) return false;
+        if (!span_fits(off, 1, 0, len, buffers[(size_t)buffer].second)) return false;
         ptr = buffers[(size_t)buffer].first + off;
         return true;
     };
@@ -472,7 +491,7 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
         const Json &j = jacc->at((size_t)idx);
         a.componentType = j.get("componentType") ? j.get("componentType")->integer(0) : 0;
         a.ncomp = j.get("type") ? type_ncomp(j.get("type")->str) : 0;
-        a.count = j.get("count") ? (size_t)j.get("count")->number(0) : 0;
+        if (!json_size(j.get("count"), 0, a.count)) return false;
         a.normalized = j.get("normalized") && j.get("normalized")->b;
         const size_t cs = comp_size(a.componentType);
         if (!cs || !a.ncomp) return false;
@@ -483,9 +502,10 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
         if (bv) {
             const uint8_t *ptr; size_t len, stride;
             if (!view_span(bv->integer(-1), ptr, len, stride)) return false;
-            size_t off = j.get("byteOffset") ? (size_t)j.get("byteOffset")->number(0) : 0;
+            size_t off;
+            if (!json_size(j.get("byteOffset"), 0, off)) return false;
             a.stride = stride ? stride : elem;
-            if (a.count && off + (a.count - 1) * a.stride + elem > len) return false;
+            if (!span_fits(off, a.count, a.stride, elem, len)) return false;
             a.base = ptr + off;
         }
         if (!sparse) return true;
@@ -494,15 +514,15 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
         auto dense = std::make_shared<std::vector<uint8_t>>(a.count * elem, (uint8_t)0);
         if (bv) for (size_t i = 0; i < a.count; i++) memcpy(dense->data() + i * elem, a.base + i * a.stride, elem);
         const Json *si = sparse->get("indices"), *sv = sparse->get("values");
-        const size_t n = sparse->get("count") ? (size_t)sparse->get("count")->number(0) : 0;
+        size_t n, ioff, voff;
+        if (!json_size(sparse->get("count"), 0, n)) return false;
         if (!si || !sv || !si->get("bufferView") || !sv->get("bufferView")) return false;
         const uint8_t *ip, *vp; size_t il, vl, st;
         if (!view_span(si->get("bufferView")->integer(-1), ip, il, st) || !view_span(sv->get("bufferView")->integer(-1), vp, vl, st)) return false;
-        const size_t ioff = si->get("byteOffset") ? (size_t)si->get("byteOffset")->number(0) : 0;
-        const size_t voff = sv->get("byteOffset") ? (size_t)sv->get("byteOffset")->number(0) : 0;
+        if (!json_size(si->get("byteOffset"), 0, ioff) || !json_size(sv->get("byteOffset"), 0, voff)) return false;
         const int ict = si->get("componentType") ? si->get("componentType")->integer(0) : 0;
         const size_t ics = comp_size(ict);
-        if (!(ict == 5121 || ict == 5123 || ict == 5125) || ioff + n * ics > il || voff + n * elem > vl) return false;
+        if (!(ict == 5121 || ict == 5123 || ict == 5125) || !span_fits(ioff, n, ics, ics, il) || !span_fits(voff, n, elem, elem, vl)) return false;
         for (size_t k = 0; k < n; k++) {
             uint32_t at = 0;
             memcpy(&at, ip + ioff + k * ics, ics);               // little-endian host
@@ -657,9 +677,13 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
         }
         return m;
     };
+    // glTF 2.0 section 3.5.2: the node hierarchy is a set of strict trees (no node has two parents), so a walk never
+    // visits more nodes than the file holds; this also stops cycles and DAGs that instantiate exponentially
     bool node_err = false;
+    size_t visits = 0;
     auto walk = [&](auto &&self, int node, const M4 &parent, int depth) -> void {
-        if (!jnodes || node < 0 || (size_t)node >= jnodes->size() || depth > 256) { node_err = true; return; }
+        if (node_err) return;
+        if (!jnodes || node < 0 || (size_t)node >= jnodes->size() || depth > 256 || ++visits > jnodes->size()) { node_err = true; return; }
         const Json &n = jnodes->at((size_t)node);
         M4 world = m4_mul(parent, local_matrix(n));
         if (n.get("mesh")) instances.push_back({world, n.get("mesh")->integer(-1)});
@@ -670,7 +694,7 @@ static pt_status load_glb_impl(const char *path, HostSceneImpl &scene)
         const Json *sn = jscenes->at((size_t)scene_idx).get("nodes");
         if (sn) for (size_t i = 0; i < sn->size(); i++) walk(walk, sn->at(i).integer(-1), m4_identity(), 0);
     }
-    if (node_err) return set_error(PT_ERR_IO, "bad node index in GLB scene graph");
+    if (node_err) return set_error(PT_ERR_IO, "bad node index, cycle or shared node in the glTF scene graph");
 
     // ---- triangles, grouped by material index ascending (PreTransformVertices), then by
     // instance order, then by primitive order.

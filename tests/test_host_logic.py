@@ -324,6 +324,23 @@ def test_glb_loader_handcrafted_files(pt, tmp_path):
     p.write_bytes(_minimal_glb(bad, pos + idx))
     with pytest.raises(RuntimeError):
         pt.SceneLoader().load(str(p))
+    # sizes whose products wrap 64 bits, or that are not sizes at all (found by tools/loader_fuzz/fuzz_gltf.py: count x stride
+    # wrapped to a small number and the accessor read far outside its buffer)
+    for acc, view in (({"count": 2 ** 47}, {"byteStride": 2 ** 20}), ({"count": 2 ** 44 + 1}, {"byteStride": 2 ** 20}),
+                      ({"count": 1e308}, {}), ({"count": -3}, {}), ({"byteOffset": 2 ** 64}, {}), ({"byteOffset": -12}, {}),
+                      ({}, {"byteOffset": 2 ** 63}), ({}, {"byteLength": 2 ** 64 + 36}), ({"count": "3"}, {})):
+        bad = dict(base, nodes=[{"mesh": 0}])
+        bad["accessors"] = [dict(base["accessors"][0], **acc)]
+        bad["bufferViews"] = [dict(base["bufferViews"][0], **view)]
+        p.write_bytes(_minimal_glb(bad, pos))
+        with pytest.raises(RuntimeError):
+            pt.SceneLoader().load(str(p))
+    # the node hierarchy must be a strict tree: cycles and shared children (which instantiate exponentially) are refused
+    for nodes in ([{"mesh": 0, "children": [0]}], [{"mesh": 0, "children": [1]}, {"children": [0]}],
+                  [{"mesh": 0, "children": [1] * 40}] + [{"mesh": 0, "children": [k + 2] * 40} for k in range(6)] + [{"mesh": 0}]):
+        p.write_bytes(_minimal_glb(dict(base, nodes=nodes), pos))
+        with pytest.raises(RuntimeError):
+            pt.SceneLoader().load(str(p))
     whole = _minimal_glb(dict(base, nodes=[{"mesh": 0}]), pos)
     for cut in (10, 20, len(whole) - 5):
         p.write_bytes(whole[:cut])
