@@ -507,9 +507,11 @@ pt_status pt_device_create(int device_index, pt_device **out)
     PT_HIP(hipSetDevice(device_index));
     std::unique_ptr<pt_device> d(new pt_device());
     d->index = device_index;
-    if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;      // diagnostic A/B switches
-    if (getenv("PTAMD_SPEC_PCT")) d->spec_pct = atoi(getenv("PTAMD_SPEC_PCT"));
-    if (getenv("PTAMD_COOP")) d->coop_mode = atoi(getenv("PTAMD_COOP"));
+    // diagnostic A/B switches for the sweeps under tools/ (DESIGN.md section 4b); none changes a byte of output,
+    // out-of-range values are ignored
+    if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;
+    if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 100) d->spec_pct = v; }
+    if (const char *e = getenv("PTAMD_COOP")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->coop_mode = v; }
     {
         hipDeviceProp_t prop;
         PT_HIP(hipGetDeviceProperties(&prop, device_index));
