@@ -39,8 +39,11 @@ enum {
     PT_ERR_IO = 5,           /* file missing / malformed                                       */
     PT_ERR_UNSUPPORTED = 6,  /* valid input this build does not handle                         */
     PT_ERR_NO_SCENE = 7,     /* render before pt_upload_scene / pt_bind_framebuffer            */
-    PT_ERR_NO_DEVICE = 8     /* no usable gfx950 device: the HIP path is mandatory, there is no
+    PT_ERR_NO_DEVICE = 8,    /* no usable gfx950 device: the HIP path is mandatory, there is no
                                 CPU fallback                                                   */
+    PT_ERR_NOMEM = 9,        /* a host allocation failed (std::bad_alloc / length_error)        */
+    PT_ERR_INTERNAL = 10     /* any other C++ exception, caught at the boundary: nothing is ever
+                                thrown across this C ABI                                        */
 };
 
 /* ------------------------------------------------------------------ host data model -- */

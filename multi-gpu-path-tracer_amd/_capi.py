@@ -15,6 +15,7 @@ PT_OK = 0
 STATUS_NAMES = {
     0: "PT_OK", 1: "PT_ERR_INVALID", 2: "PT_ERR_HIP", 3: "PT_ERR_NO_LIGHTS", 4: "PT_ERR_STACK",
     5: "PT_ERR_IO", 6: "PT_ERR_UNSUPPORTED", 7: "PT_ERR_NO_SCENE", 8: "PT_ERR_NO_DEVICE",
+    9: "PT_ERR_NOMEM", 10: "PT_ERR_INTERNAL",
 }
 
 # numpy mirrors of the PODs (HostScene.h:28-59, CameraConfig.h:5-17, DevicePathTracer.h:19-25)

@@ -9,24 +9,43 @@
 #include "pt_internal.h"
 
 #include <algorithm>
+#include <cmath>
+#include <future>
+#include <thread>
 
 namespace pt {
 namespace {
 
 struct Builder {
-    const float *pos;                 // 9 floats per triangle
-    std::vector<float> cx, cy, cz;    // triangle.h:27 centroid = (v0+v1+v2)*0.3333f
+    // Working copy of the triangles, permuted in lockstep with out.indices (rec[i] describes triangle
+    // out.indices[i]): a node's triangles are then one contiguous stream instead of a gather through the
+    // permutation, which is what an 8 M-triangle build spends its time on otherwise.
+    struct Rec { float p[9]; float c[3]; };      // vertices; triangle.h:27 centroid = (v0+v1+v2)*0.3333f
+    std::vector<Rec> rec;
     RefBvh &out;
-    uint32_t nodesUsed = 1;
 
-    explicit Builder(const float *p, size_t n, RefBvh &o) : pos(p), out(o)
+    // Host threads: the reference builds with one (device) thread, and what it builds -- topology, node numbers,
+    // triangle permutation -- is observable, so threads are used only where the result cannot depend on them:
+    //  * the split candidates of a big node are costed, and its bounds computed, over chunks of its triangles
+    //    in parallel: counts add up and fminf / fmaxf over a set do not depend on the order (NaN coordinates
+    //    are ignored by both forms; a box never ends at a signed zero because it always contains the default
+    //    box [-5e-6, 5e-6]^3, so the one order-dependent case of fminf / fmaxf cannot be the result);
+    //  * the two subtrees of a big node are built concurrently in node pools of their own (they own disjoint
+    //    ranges of `indices`); the node numbers of the serial build (children allocated as a pair, then the
+    //    whole left subtree, then the right one: bvh.h:74-93) are assigned afterwards by renumber().
+    // The partition (bvh.h:56-72) defines the triangle order and stays serial.
+    static constexpr uint32_t kChunkParallelMin = 1u << 17;
+    static constexpr uint32_t kSubtreeParallelMin = 1u << 16;
+    typedef std::vector<RefNode> Pool;
+
+    explicit Builder(const float *pos, size_t n, RefBvh &o) : rec(n), out(o)
     {
-        cx.resize(n); cy.resize(n); cz.resize(n);
         for (size_t i = 0; i < n; i++) {
             const float *t = pos + 9 * i;
-            cx[i] = ((t[0] + t[3]) + t[6]) * 0.3333f;
-            cy[i] = ((t[1] + t[4]) + t[7]) * 0.3333f;
-            cz[i] = ((t[2] + t[5]) + t[8]) * 0.3333f;
+            for (int k = 0; k < 9; k++) rec[i].p[k] = t[k];
+            rec[i].c[0] = ((t[0] + t[3]) + t[6]) * 0.3333f;
+            rec[i].c[1] = ((t[1] + t[4]) + t[7]) * 0.3333f;
+            rec[i].c[2] = ((t[2] + t[5]) + t[8]) * 0.3333f;
         }
     }
 
@@ -39,15 +58,21 @@ struct Builder {
         b.ymin = 0.0f - padding; b.ymax = 0.0f + padding;
         b.zmin = 0.0f - padding; b.zmax = 0.0f + padding;
     }
-    // aabb::extend, aabb.h:80-88, for the three vertices of triangle `tri`.
-    void box_extend_tri(RefNode &b, int tri) const
+    // fminf(t, b) / fmaxf(t, b) of aabb::extend (aabb.h:80-88) as one minss / maxss: a NaN coordinate t is
+    // ignored by both forms, b is never NaN, and the two forms differ only in which zero they return for
+    // (+0, -0) -- which no box bound can be, since every box contains [-5e-6, 5e-6]^3 (partial boxes that start
+    // empty are merged into such a box before they are used).  A libm call per min/max was 3/4 of the build.
+    static float lo(float t, float b) { return t < b ? t : b; }
+    static float hi(float t, float b) { return t > b ? t : b; }
+    // aabb::extend for the three vertices of the triangle at position `at` of the permutation.
+    void box_extend_tri(RefNode &b, uint32_t at) const
     {
-        const float *t = pos + 9 * (size_t)tri;
+        const float *t = rec[at].p;
         for (int k = 0; k < 3; k++) {
-            b.xmin = fminf(t[3 * k + 0], b.xmin); b.ymin = fminf(t[3 * k + 1], b.ymin);
-            b.zmin = fminf(t[3 * k + 2], b.zmin);
-            b.xmax = fmaxf(t[3 * k + 0], b.xmax); b.ymax = fmaxf(t[3 * k + 1], b.ymax);
-            b.zmax = fmaxf(t[3 * k + 2], b.zmax);
+            b.xmin = lo(t[3 * k + 0], b.xmin); b.ymin = lo(t[3 * k + 1], b.ymin);
+            b.zmin = lo(t[3 * k + 2], b.zmin);
+            b.xmax = hi(t[3 * k + 0], b.xmax); b.ymax = hi(t[3 * k + 1], b.ymax);
+            b.zmax = hi(t[3 * k + 2], b.zmax);
         }
     }
     static float box_area(const RefNode &b)          // aabb.h:75-78 (half area)
@@ -55,71 +80,171 @@ struct Builder {
         float ex = b.xmax - b.xmin, ey = b.ymax - b.ymin, ez = b.zmax - b.zmin;
         return ex * ey + ey * ez + ez * ex;
     }
-    float centroid(int tri, int axis) const
+    void update_bounds(RefNode &n) const              // bvh.h:96-106
     {
-        return axis == 0 ? cx[tri] : (axis == 1 ? cy[tri] : cz[tri]);
-    }
-    void update_bounds(uint32_t idx)                  // bvh.h:96-106
-    {
-        RefNode &n = out.nodes[idx];
+        if (n.triCount >= kChunkParallelMin) { update_bounds_chunked(n); return; }
         box_default(n);
-        for (uint32_t i = 0; i < n.triCount; i++) box_extend_tri(n, out.indices[n.firstTri + i]);
+        for (uint32_t i = 0; i < n.triCount; i++) box_extend_tri(n, n.firstTri + i);
     }
-    float evaluate_sah(const RefNode &n, int axis, float p) const     // bvh.h:144-176
+    static void box_empty(RefNode &b)
     {
-        RefNode lb, rb;
-        box_default(lb); box_default(rb);
-        int lc = 0, rc = 0;
-        for (uint32_t i = 0; i < n.triCount; i++) {
-            int tri = out.indices[n.firstTri + i];
-            if (centroid(tri, axis) < p) { lc++; box_extend_tri(lb, tri); }
-            else                         { rc++; box_extend_tri(rb, tri); }
-        }
-        float cost = (float)lc * box_area(lb) + (float)rc * box_area(rb);
-        return cost > 0 ? cost : 1e30f;
+        b.xmin = b.ymin = b.zmin = INFINITY; b.xmax = b.ymax = b.zmax = -INFINITY;
     }
-    void subdivide(uint32_t idx, uint32_t level)      // bvh.h:35-94
+    static void box_merge(RefNode &b, const RefNode &part)          // same forms as box_extend_tri
     {
-        if (level > out.depth) out.depth = level;
-        {
-            RefNode &n = out.nodes[idx];
-            if (n.triCount <= 5) return;
+        b.xmin = lo(part.xmin, b.xmin); b.ymin = lo(part.ymin, b.ymin); b.zmin = lo(part.zmin, b.zmin);
+        b.xmax = hi(part.xmax, b.xmax); b.ymax = hi(part.ymax, b.ymax); b.zmax = hi(part.zmax, b.zmax);
+    }
+    static unsigned chunk_threads(uint32_t count)
+    {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        return std::min<unsigned>(std::min(hw, 16u), std::max<uint32_t>(1, count >> 15));
+    }
+    // evaluateSAH (bvh.h:144-176) for all candidates of a node at once.  The reference makes one pass over the
+    // node's triangles per candidate (nine passes, each extending one of two boxes by every triangle); here a
+    // triangle is classified against the three planes of an axis (the same `centroid < pos` comparisons) and
+    // extends ONE box per axis, that of its comparison pattern; a candidate's left / right box is then the union
+    // of the pattern boxes on its side and its counts their sums.  Same boxes (fminf / fmaxf over the same
+    // sets, see the note on order above), same counts, a third of the box updates and one gather per triangle.
+    struct Patterns { RefNode box[3][8]; uint32_t cnt[3][8]; };
+    void classify(const RefNode &n, uint32_t lo, uint32_t hi, const float (*plane)[3], const bool *axis_on, Patterns &P) const
+    {
+        for (int a = 0; a < 3; a++) for (int k = 0; k < 8; k++) { box_empty(P.box[a][k]); P.cnt[a][k] = 0; }
+        for (uint32_t i = lo; i < hi; i++) {
+            const uint32_t at = n.firstTri + i;
+            const float *c3 = rec[at].c;
+            for (int a = 0; a < 3; a++) {
+                if (!axis_on[a]) continue;
+                const int k = (c3[a] < plane[a][0] ? 1 : 0) | (c3[a] < plane[a][1] ? 2 : 0) | (c3[a] < plane[a][2] ? 4 : 0);
+                P.cnt[a][k]++;
+                box_extend_tri(P.box[a][k], at);
+            }
         }
-        RefNode n = out.nodes[idx];
+    }
+    // cost[a][i] of the plane i of axis a (unused entries untouched)
+    void evaluate_candidates(const RefNode &n, const float (*plane)[3], const bool *axis_on, float (*cost)[3]) const
+    {
+        const unsigned T = n.triCount >= kChunkParallelMin ? chunk_threads(n.triCount) : 1;
+        std::vector<Patterns> parts(T);
+        auto work = [&](unsigned t) {
+            classify(n, (uint32_t)((uint64_t)n.triCount * t / T), (uint32_t)((uint64_t)n.triCount * (t + 1) / T), plane, axis_on, parts[t]);
+        };
+        std::vector<std::future<void>> jobs;
+        for (unsigned t = 1; t < T; t++) jobs.push_back(std::async(std::launch::async, work, t));
+        work(0);
+        for (auto &j : jobs) j.get();
+        for (int a = 0; a < 3; a++) {
+            if (!axis_on[a]) continue;
+            for (int i = 0; i < 3; i++) {
+                RefNode lb, rb;
+                box_default(lb); box_default(rb);
+                uint32_t lc = 0, rc = 0;
+                for (unsigned t = 0; t < T; t++)
+                    for (int k = 0; k < 8; k++) {
+                        if ((k >> i) & 1) { box_merge(lb, parts[t].box[a][k]); lc += parts[t].cnt[a][k]; }
+                        else              { box_merge(rb, parts[t].box[a][k]); rc += parts[t].cnt[a][k]; }
+                    }
+                const float v = (float)(int)lc * box_area(lb) + (float)(int)rc * box_area(rb);
+                cost[a][i] = v > 0 ? v : 1e30f;
+            }
+        }
+    }
+    void update_bounds_chunked(RefNode &n) const
+    {
+        const unsigned T = chunk_threads(n.triCount);
+        std::vector<RefNode> parts(T);
+        auto work = [&](unsigned t) {
+            box_empty(parts[t]);
+            const uint32_t lo = (uint32_t)((uint64_t)n.triCount * t / T), hi = (uint32_t)((uint64_t)n.triCount * (t + 1) / T);
+            for (uint32_t i = lo; i < hi; i++) box_extend_tri(parts[t], n.firstTri + i);
+        };
+        std::vector<std::future<void>> jobs;
+        for (unsigned t = 1; t < T; t++) jobs.push_back(std::async(std::launch::async, work, t));
+        work(0);
+        for (auto &j : jobs) j.get();
+        box_default(n);
+        for (unsigned t = 0; t < T; t++) box_merge(n, parts[t]);
+    }
+    // Builds the subtree under pool[idx] (node numbers local to `pool`); returns its deepest level.
+    uint32_t subdivide(Pool &pool, uint32_t idx, uint32_t level, int forks)      // bvh.h:35-94
+    {
+        if (pool[idx].triCount <= 5) return level;
+        const RefNode n = pool[idx];
         int axis = 0;
         float split = 0.0f, best = 1e30f;
+        float plane[3][3], cost[3][3];
+        bool axis_on[3];
         for (int a = 0; a < 3; a++) {                 // bvh.h:108-137
             float bmin = a == 0 ? n.xmin : (a == 1 ? n.ymin : n.zmin);
             float bmax = a == 0 ? n.xmax : (a == 1 ? n.ymax : n.zmax);
-            if (bmin == bmax) continue;
+            axis_on[a] = !(bmin == bmax);
             float scale = (bmax - bmin) / 4;
-            for (uint32_t i = 1; i < 4; i++) {
-                float cand = bmin + (float)i * scale;
-                float cost = evaluate_sah(n, a, cand);
-                if (cost < best) { split = cand; axis = a; best = cost; }
-            }
+            for (uint32_t i = 1; i < 4; i++) plane[a][i - 1] = bmin + (float)i * scale;
         }
+        evaluate_candidates(n, plane, axis_on, cost);
+        for (int a = 0; a < 3; a++)                   // first strictly lower cost wins, axis 0..2, i 1..3
+            for (int i = 0; i < 3; i++)
+                if (axis_on[a] && cost[a][i] < best) { split = plane[a][i]; axis = a; best = cost[a][i]; }
         float nosplit = (float)n.triCount * box_area(n);              // bvh.h:139-142
-        if (best >= nosplit) return;
+        if (best >= nosplit) return level;
         int i = (int)n.firstTri;
         int j = i + (int)n.triCount - 1;
         while (i <= j) {                               // bvh.h:56-72
-            if (centroid(out.indices[i], axis) < split) i++;
-            else std::swap(out.indices[i], out.indices[j--]);
+            if (rec[(size_t)i].c[axis] < split) i++;
+            else { std::swap(rec[(size_t)i], rec[(size_t)j]); std::swap(out.indices[i], out.indices[j--]); }
         }
         int leftCount = i - (int)n.firstTri;
-        if (leftCount == 0 || leftCount == (int)n.triCount) return;
-        uint32_t l = nodesUsed++, r = nodesUsed++;
-        RefNode &ln = out.nodes[l];
-        RefNode &rn = out.nodes[r];
+        if (leftCount == 0 || leftCount == (int)n.triCount) return level;
+        RefNode ln, rn;
         ln.left = ln.right = 0; rn.left = rn.right = 0;
         ln.firstTri = n.firstTri;  ln.triCount = (uint32_t)leftCount;
         rn.firstTri = (uint32_t)i; rn.triCount = n.triCount - (uint32_t)leftCount;
-        out.nodes[idx].left = l; out.nodes[idx].right = r; out.nodes[idx].triCount = 0;
-        update_bounds(l);
-        update_bounds(r);
-        subdivide(l, level + 1);
-        subdivide(r, level + 1);
+        const bool fork = forks > 0 && std::min(ln.triCount, rn.triCount) >= kSubtreeParallelMin;
+        uint32_t deepest;
+        if (fork) {
+            Pool other(1, ln);
+            auto fut = std::async(std::launch::async, [this, &other, level, forks] {
+                update_bounds(other[0]);
+                return subdivide(other, 0, level + 1, forks - 1);
+            });
+            const uint32_t r = (uint32_t)pool.size();
+            pool.push_back(rn);
+            update_bounds(pool[r]);
+            deepest = subdivide(pool, r, level + 1, forks - 1);
+            deepest = std::max(deepest, fut.get());
+            const uint32_t base = (uint32_t)pool.size();
+            for (RefNode nd : other) {
+                if (nd.triCount == 0) { nd.left += base; nd.right += base; }
+                pool.push_back(nd);
+            }
+            pool[idx].left = base; pool[idx].right = r;
+        } else {
+            const uint32_t l = (uint32_t)pool.size();
+            pool.push_back(ln); pool.push_back(rn);
+            update_bounds(pool[l]);
+            update_bounds(pool[l + 1]);
+            pool[idx].left = l; pool[idx].right = l + 1;
+            deepest = subdivide(pool, l, level + 1, forks);
+            deepest = std::max(deepest, subdivide(pool, l + 1, level + 1, forks));
+        }
+        pool[idx].triCount = 0;
+        return deepest;
+    }
+    // The serial build's numbering (bvh.h:74-75,92-93): `nodesUsed++` twice for the children, then everything
+    // the left subtree allocates, then everything the right subtree allocates.
+    void renumber(const Pool &pool, uint32_t old_idx, uint32_t new_idx, uint32_t &used)
+    {
+        RefNode n = pool[old_idx];
+        if (n.triCount == 0) {
+            const uint32_t l = used++, r = used++;
+            const uint32_t ol = n.left, orr = n.right;
+            n.left = l; n.right = r;
+            out.nodes[new_idx] = n;
+            renumber(pool, ol, l, used);
+            renumber(pool, orr, r, used);
+        } else {
+            out.nodes[new_idx] = n;
+        }
     }
 
     // Worst-case use of the 64-entry traversal stack of bvh.h:179 (sentinel included):
@@ -147,17 +272,20 @@ struct Builder {
 void build_reference_bvh(const float *positions9, size_t n_tris, RefBvh &out)
 {
     out = RefBvh();
-    out.nodes.assign(2 * n_tris - 1, RefNode());
     out.indices.resize(n_tris);
     for (size_t i = 0; i < n_tris; i++) out.indices[i] = (int)i;
     Builder b(positions9, n_tris, out);
-    RefNode &root = out.nodes[0];
-    root.left = root.right = 0;
-    root.firstTri = 0;
-    root.triCount = (uint32_t)n_tris;
-    b.update_bounds(0);
-    b.subdivide(0, 0);
-    out.nodes.resize(b.nodesUsed);
+    Builder::Pool pool;
+    pool.reserve(std::min<size_t>(2 * n_tris, (size_t)1 << 22));
+    pool.emplace_back();
+    pool[0].left = pool[0].right = 0;
+    pool[0].firstTri = 0;
+    pool[0].triCount = (uint32_t)n_tris;
+    b.update_bounds(pool[0]);
+    out.depth = b.subdivide(pool, 0, 0, 6);
+    out.nodes.assign(pool.size(), RefNode());
+    uint32_t used = 1;
+    b.renumber(pool, 0, 0, used);
     for (const RefNode &n : out.nodes) {
         if (n.triCount != 0) {
             out.leaves++;

@@ -1,6 +1,9 @@
 // pt_common.cpp -- error reporting and the host-side task generators of the C ABI.
 #include "pt_internal.h"
 
+#include <new>
+#include <stdexcept>
+
 #include <cstring>
 #include <vector>
 
@@ -14,6 +17,18 @@ pt_status set_error(pt_status code, const std::string &msg)
     return code;
 }
 void clear_error() { g_error.clear(); }
+pt_status exception_status() noexcept
+{
+    try {
+        try { throw; }
+        catch (const std::bad_alloc &) { return set_error(PT_ERR_NOMEM, "host allocation failed"); }
+        catch (const std::length_error &e) { return set_error(PT_ERR_NOMEM, std::string("host allocation failed: ") + e.what()); }
+        catch (const std::exception &e) { return set_error(PT_ERR_INTERNAL, std::string("internal error: ") + e.what()); }
+        catch (...) { return set_error(PT_ERR_INTERNAL, "internal error: unknown exception"); }
+    } catch (...) {
+        return PT_ERR_NOMEM;       // even the message could not be stored
+    }
+}
 
 } // namespace pt
 
@@ -26,7 +41,7 @@ const char *pt_version(void) { return "ptamd 0.1 (gfx950)"; }
 
 pt_status pt_host_bvh_build(const pt_triangle *tris, size_t n, pt_bvh_info *info, float *bounds6,
                             uint32_t *links4, int *tri_indices)
-{
+try {
     clear_error();
     if (!tris || n == 0) return set_error(PT_ERR_INVALID, "no triangles");
     std::vector<float> pos(9 * n);
@@ -50,10 +65,10 @@ pt_status pt_host_bvh_build(const pt_triangle *tris, size_t n, pt_bvh_info *info
     }
     if (tri_indices) for (size_t i = 0; i < n; i++) tri_indices[i] = bvh.indices[i];
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_host_sah_build(const pt_triangle *tris, size_t n, pt_bvh_info *info, float *pairs16, int *order)
-{
+try {
     clear_error();
     if (!tris || n == 0) return set_error(PT_ERR_INVALID, "no triangles");
     std::vector<float> pos(9 * n);
@@ -74,14 +89,14 @@ pt_status pt_host_sah_build(const pt_triangle *tris, size_t n, pt_bvh_info *info
     if (pairs16) memcpy(pairs16, bvh.pairs.data(), bvh.pairs.size() * sizeof(NodePair));
     if (order) memcpy(order, bvh.order.data(), n * sizeof(int));
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 // RenderManager::getTaskLayout (RenderManager.h:42-59) + TaskGenerator::generateEqualTasks
 // (TaskGenerator.h:58-80): rows of at most max_tasks_in_row rectangles; the last column
 // and the last row absorb the remainders.
 pt_status pt_tasks_equal_layout(int task_count, int max_tasks_in_row, int width, int height,
                                 pt_task *out)
-{
+try {
     clear_error();
     if (task_count <= 0 || max_tasks_in_row <= 0 || width <= 0 || height <= 0 || !out)
         return set_error(PT_ERR_INVALID, "bad task layout request");
@@ -110,11 +125,11 @@ pt_status pt_tasks_equal_layout(int task_count, int max_tasks_in_row, int width,
     }
     for (int idx : layout.back()) out[idx].height = height - out[idx].offset_y;
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 // TaskGenerator::generateEqualTasks(task_count, width, height), TaskGenerator.h:46-55.
 pt_status pt_tasks_equal_row(int task_count, int width, int height, pt_task *out)
-{
+try {
     clear_error();
     if (task_count <= 0 || width <= 0 || height <= 0 || !out)
         return set_error(PT_ERR_INVALID, "bad task request");
@@ -122,14 +137,14 @@ pt_status pt_tasks_equal_row(int task_count, int width, int height, pt_task *out
     for (int i = 0; i < task_count - 1; i++) out[i] = {task_w, height, i * task_w, 0};
     out[task_count - 1] = {width - (task_count - 1) * task_w, height, (task_count - 1) * task_w, 0};
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 // Multi-GPU partition: full-width bands of band_rows framebuffer rows, dealt
 // round-robin to ranks.  Framebuffer row r (0 = top) is task row y = H-1-r, so band b covers
 // fb rows [b*band_rows, min(H,(b+1)*band_rows)) = task offset_y = H - end, height = end-start.
 pt_status pt_tasks_row_bands(int width, int height, int band_rows, int n_ranks, int rank,
                              pt_task *out, int max_tasks, int *n_out)
-{
+try {
     clear_error();
     if (width <= 0 || height <= 0 || band_rows <= 0 || (band_rows & 1) || n_ranks <= 0 || rank < 0 ||
         rank >= n_ranks || !n_out || (max_tasks > 0 && !out))
@@ -145,6 +160,6 @@ pt_status pt_tasks_row_bands(int width, int height, int band_rows, int n_ranks, 
     *n_out = n;
     if (n > max_tasks) return set_error(PT_ERR_INVALID, "out_tasks too small");
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 } // extern "C"

@@ -496,7 +496,7 @@ static pt_status drain_events(pt_device *d)
 extern "C" {
 
 pt_status pt_device_create(int device_index, pt_device **out)
-{
+try {
     clear_error();
     if (!out) return set_error(PT_ERR_INVALID, "null out pointer");
     int count = 0;
@@ -521,10 +521,10 @@ pt_status pt_device_create(int device_index, pt_device **out)
     PT_HIP(hipMemset(d->d_counters, 0, 8 * sizeof(unsigned long long)));
     *out = d.release();
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_device_destroy(pt_device *dev)
-{
+try {
     clear_error();
     if (!dev) return PT_OK;
     (void)hipSetDevice(dev->index);
@@ -536,11 +536,11 @@ pt_status pt_device_destroy(pt_device *dev)
     for (auto &pr : dev->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete dev;
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, const pt_material *mats,
                           size_t m, const pt_texture *texs, size_t k)
-{
+try {
     clear_error();
     if (!dev || !tris || !mats || n == 0 || m == 0 || (k && !texs))
         return set_error(PT_ERR_INVALID, "scene needs at least one triangle and one material");
@@ -608,9 +608,10 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
 
     // create_world, DevicePathTracer.h:134-146 -> BVH::BVH, bvh.h:20-33, on the host
     const bool sah = dev->bvh_mode == 1;
-    // The reference tree is also built under the SAH option when that is affordable: its visit
-    // order ranks the triangles for exact-tie resolution.  (8M triangles: 17 s on one host core.)
-    const bool build_ref = !sah || n <= (size_t)1 << 20;
+    // The reference tree is also built under the SAH option: its visit order ranks the triangles for
+    // exact-tie resolution (8.4 M triangles: ~2 s on 8 host cores, pt_bvh.cpp).  Beyond 2^25 triangles it is
+    // skipped and ties resolve by face index.
+    const bool build_ref = !sah || n <= (size_t)1 << 25;
     RefBvh bvh;
     if (build_ref) {
         build_reference_bvh(pos.data(), n, bvh);
@@ -770,18 +771,18 @@ pt_status pt_upload_scene(pt_device *dev, const pt_triangle *tris, size_t n, con
     dev->queue_entries = (int)std::min<uint32_t>(std::max<uint32_t>(dev->bvh.leaves + 1, 4), 12);
     dev->has_scene = true;
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_upload_host_scene(pt_device *dev, const pt_host_scene *scene)
-{
+try {
     if (!scene) { clear_error(); return set_error(PT_ERR_INVALID, "null scene"); }
     const HostSceneImpl &s = host_scene_impl(scene);
     return pt_upload_scene(dev, s.triangles.data(), s.triangles.size(), s.materials.data(),
                            s.materials.size(), s.textures.data(), s.textures.size());
-}
+} PT_CATCH_ALL
 
 pt_status pt_bind_framebuffer(pt_device *dev, int width, int height, uint8_t *rgb, uint8_t *yuv)
-{
+try {
     clear_error();
     if (!dev || width <= 0 || height <= 0 || !rgb || !yuv) return set_error(PT_ERR_INVALID, "bad framebuffer");
     if ((long long)width * (long long)height > (1ll << 30)) return set_error(PT_ERR_INVALID, "framebuffer too large");
@@ -789,19 +790,19 @@ pt_status pt_bind_framebuffer(pt_device *dev, int width, int height, uint8_t *rg
         return set_error(PT_ERR_UNSUPPORTED, "odd framebuffer sizes: the reference's YUV420 indexing (DevicePathTracer.h:107-119) writes past its planes; only even widths and heights are accepted");
     dev->W = width; dev->H = height; dev->rgb = rgb; dev->yuv = yuv;
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_set_bvh_mode(pt_device *dev, int mode)
-{
+try {
     clear_error();
     if (!dev || mode < 0 || mode > 1) return set_error(PT_ERR_INVALID, "bvh mode must be 0 (reference topology) or 1 (SAH tree)");
     dev->bvh_mode = mode;
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_set_legacy_scene(pt_device *dev, const pt_legacy_material *materials, size_t n_materials,
                               const pt_sphere *spheres, size_t n_spheres)
-{
+try {
     clear_error();
     if (!dev || (n_materials && !materials) || (n_spheres && !spheres)) return set_error(PT_ERR_INVALID, "null argument");
     for (size_t i = 0; i < n_materials; i++)
@@ -811,18 +812,18 @@ pt_status pt_set_legacy_scene(pt_device *dev, const pt_legacy_material *material
     dev->legacy_next.assign(materials, materials + n_materials);
     dev->spheres_next.assign(spheres, spheres + n_spheres);
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_set_cooperative_mode(pt_device *dev, int mode)
-{
+try {
     clear_error();
     if (!dev || mode < -1 || mode > 1) return set_error(PT_ERR_INVALID, "mode must be -1 (auto), 0 (off) or 1 (on)");
     dev->coop_mode = mode;
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_set_tile_schedule(pt_device *dev, int mode)
-{
+try {
     clear_error();
     if (!dev || mode < 0 || mode > 1) return set_error(PT_ERR_INVALID, "mode must be 0 (raster order) or 1 (cost-ordered)");
     PT_HIP(hipSetDevice(dev->index));
@@ -831,10 +832,10 @@ pt_status pt_set_tile_schedule(pt_device *dev, int mode)
     dev->tile_schedule = mode;
     drop_schedules(dev);
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_set_traversal_mode(pt_device *dev, int mode)
-{
+try {
     clear_error();
     if (!dev || mode < 0 || mode > 3) return set_error(PT_ERR_INVALID, "mode must be 0 (auto), 1 (per-lane), 2 (wave-uniform, mask) or 3 (wave-uniform, stack)");
     const int saved = dev->force_walk;
@@ -848,15 +849,15 @@ pt_status pt_set_traversal_mode(pt_device *dev, int mode)
         dev->walk = w;
     }
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_set_thread_block_size(pt_device *dev, unsigned x, unsigned y)
-{
+try {
     clear_error();
     if (!dev || x == 0 || y == 0) return set_error(PT_ERR_INVALID, "bad thread block size");
     dev->block_x = x; dev->block_y = y;     // hint only: waves always cover 8x8 pixel tiles
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 // Bytes of dynamic LDS for a workgroup of `block` lanes (mirrors dev::lds_carve).
 static size_t lds_bytes(const RenderParams &P, int block, bool stage)
@@ -1020,7 +1021,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
 
 pt_status pt_render_task_async(pt_device *dev, const pt_task *task, const pt_camera *camera,
                                unsigned spp, unsigned depth, pt_stream stream)
-{
+try {
     clear_error();
     if (!dev || !task || !camera) return set_error(PT_ERR_INVALID, "null argument");
     if (task->width == 0) return PT_OK;                                  // DevicePathTracer.h:195-196
@@ -1040,11 +1041,11 @@ pt_status pt_render_task_async(pt_device *dev, const pt_task *task, const pt_cam
     P.band_rows = 0; P.band_ranks = 0; P.band_rank = 0;
     P.spp = (int)spp; P.depth = depth;
     return launch_render(dev, P, stream);
-}
+} PT_CATCH_ALL
 
 pt_status pt_render_bands_async(pt_device *dev, int band_rows, int n_ranks, int rank, const pt_camera *camera,
                                 unsigned spp, unsigned depth, pt_stream stream)
-{
+try {
     clear_error();
     if (!dev || !camera) return set_error(PT_ERR_INVALID, "null argument");
     if (!dev->has_scene || !dev->rgb) return set_error(PT_ERR_NO_SCENE, "render before pt_upload_scene / pt_bind_framebuffer");
@@ -1065,30 +1066,30 @@ pt_status pt_render_bands_async(pt_device *dev, int band_rows, int n_ranks, int 
     P.band_rows = band_rows; P.band_ranks = n_ranks; P.band_rank = rank;
     P.spp = (int)spp; P.depth = depth;
     return launch_render(dev, P, stream);
-}
+} PT_CATCH_ALL
 
 pt_status pt_stream_sync(pt_device *dev, pt_stream stream)
-{
+try {
     clear_error();
     if (!dev) return set_error(PT_ERR_INVALID, "null device");
     PT_HIP(hipSetDevice(dev->index));
     PT_HIP(hipGetLastError());
     PT_HIP(hipStreamSynchronize((hipStream_t)stream));
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_device_sync(pt_device *dev)
-{
+try {
     clear_error();
     if (!dev) return set_error(PT_ERR_INVALID, "null device");
     PT_HIP(hipSetDevice(dev->index));
     PT_HIP(hipGetLastError());
     PT_HIP(hipDeviceSynchronize());
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_stream_create(pt_device *dev, pt_stream *out)
-{
+try {
     clear_error();
     if (!dev || !out) return set_error(PT_ERR_INVALID, "null argument");
     PT_HIP(hipSetDevice(dev->index));
@@ -1096,19 +1097,19 @@ pt_status pt_stream_create(pt_device *dev, pt_stream *out)
     PT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     *out = (pt_stream)s;
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_stream_destroy(pt_device *dev, pt_stream stream)
-{
+try {
     clear_error();
     if (!dev) return set_error(PT_ERR_INVALID, "null device");
     PT_HIP(hipSetDevice(dev->index));
     if (stream) PT_HIP(hipStreamDestroy((hipStream_t)stream));
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_counters_read(pt_device *dev, pt_counters *out)
-{
+try {
     clear_error();
     if (!dev || !out) return set_error(PT_ERR_INVALID, "null argument");
     PT_HIP(hipSetDevice(dev->index));
@@ -1116,29 +1117,29 @@ pt_status pt_counters_read(pt_device *dev, pt_counters *out)
     PT_HIP(hipMemcpy(h, dev->d_counters, sizeof h, hipMemcpyDeviceToHost));
     out->paths = h[0]; out->segments = h[1]; out->box_tests = h[2]; out->tri_tests = h[3]; out->light_tests = h[4];
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_debug_counters_read(pt_device *dev, uint64_t out8[8])
-{
+try {
     clear_error();
     if (!dev || !out8) return set_error(PT_ERR_INVALID, "null argument");
     PT_HIP(hipSetDevice(dev->index));
     PT_HIP(hipMemcpy(out8, dev->d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_counters_reset(pt_device *dev)
-{
+try {
     clear_error();
     if (!dev) return set_error(PT_ERR_INVALID, "null device");
     PT_HIP(hipSetDevice(dev->index));
     PT_HIP(hipDeviceSynchronize());
     PT_HIP(hipMemset(dev->d_counters, 0, 8 * sizeof(unsigned long long)));
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_kernel_time_read(pt_device *dev, double *ms_total, uint64_t *n_launches)
-{
+try {
     clear_error();
     if (!dev || !ms_total) return set_error(PT_ERR_INVALID, "null argument");
     PT_HIP(hipSetDevice(dev->index));
@@ -1148,10 +1149,10 @@ pt_status pt_kernel_time_read(pt_device *dev, double *ms_total, uint64_t *n_laun
     *ms_total = dev->ms_total;
     if (n_launches) *n_launches = dev->launches;
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_kernel_time_reset(pt_device *dev)
-{
+try {
     clear_error();
     if (!dev) return set_error(PT_ERR_INVALID, "null device");
     PT_HIP(hipSetDevice(dev->index));
@@ -1160,10 +1161,10 @@ pt_status pt_kernel_time_reset(pt_device *dev)
     if (st != PT_OK) return st;
     dev->ms_total = 0.0; dev->launches = 0;
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_bvh_info_read(pt_device *dev, pt_bvh_info *out)
-{
+try {
     clear_error();
     if (!dev || !out) return set_error(PT_ERR_INVALID, "null argument");
     if (!dev->has_scene) return set_error(PT_ERR_NO_SCENE, "no scene uploaded");
@@ -1171,10 +1172,10 @@ pt_status pt_bvh_info_read(pt_device *dev, pt_bvh_info *out)
     out->depth = dev->bvh.depth; out->max_stack = dev->bvh.max_stack; out->lights = (uint32_t)dev->n_lights;
     out->triangles = (uint32_t)dev->n_tris;
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_bvh_copy(pt_device *dev, float *bounds6, uint32_t *links4, int *tri_indices, int *light_faces)
-{
+try {
     clear_error();
     if (!dev) return set_error(PT_ERR_INVALID, "null device");
     if (!dev->has_scene) return set_error(PT_ERR_NO_SCENE, "no scene uploaded");
@@ -1186,10 +1187,10 @@ pt_status pt_bvh_copy(pt_device *dev, float *bounds6, uint32_t *links4, int *tri
     if (tri_indices) memcpy(tri_indices, dev->bvh.indices.data(), sizeof(int) * dev->n_tris);
     if (light_faces) memcpy(light_faces, dev->light_faces.data(), sizeof(int) * dev->light_faces.size());
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_fb_alloc(pt_device *dev, int width, int height, uint8_t **rgb, uint8_t **yuv)
-{
+try {
     clear_error();
     if (!dev || width <= 0 || height <= 0 || !rgb || !yuv) return set_error(PT_ERR_INVALID, "bad argument");
     PT_HIP(hipSetDevice(dev->index));
@@ -1199,10 +1200,10 @@ pt_status pt_fb_alloc(pt_device *dev, int width, int height, uint8_t **rgb, uint
     PT_HIP(hipMemset(*rgb, 0, total * 3));
     PT_HIP(hipMemset(*yuv, 0, total + 2 * (total / 4)));
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_fb_free(pt_device *dev, uint8_t *rgb, uint8_t *yuv)
-{
+try {
     clear_error();
     if (!dev) return set_error(PT_ERR_INVALID, "null device");
     PT_HIP(hipSetDevice(dev->index));
@@ -1210,20 +1211,20 @@ pt_status pt_fb_free(pt_device *dev, uint8_t *rgb, uint8_t *yuv)
     if (rgb) PT_HIP(hipFree(rgb));
     if (yuv) PT_HIP(hipFree(yuv));
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_fb_download(pt_device *dev, const uint8_t *src, uint8_t *dst, size_t bytes, pt_stream stream)
-{
+try {
     clear_error();
     if (!dev || !src || !dst) return set_error(PT_ERR_INVALID, "null argument");
     PT_HIP(hipSetDevice(dev->index));
     PT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     PT_HIP(hipStreamSynchronize((hipStream_t)stream));
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_fb_download_task(pt_device *dev, const pt_task *task, uint8_t *rgb_host, uint8_t *yuv_host, pt_stream stream)
-{
+try {
     clear_error();
     if (!dev || !task || !rgb_host || !yuv_host) return set_error(PT_ERR_INVALID, "null argument");
     if (!dev->rgb) return set_error(PT_ERR_NO_SCENE, "no framebuffer bound");
@@ -1253,10 +1254,10 @@ pt_status pt_fb_download_task(pt_device *dev, const pt_task *task, uint8_t *rgb_
     }
     PT_HIP(hipStreamSynchronize(hs));
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_kat_arith(pt_device *dev, int op, const float *a, const float *b, float *out0, float *out1, size_t n)
-{
+try {
     clear_error();
     if (!dev || !a || !out0 || op < 0 || op > 4) return set_error(PT_ERR_INVALID, "bad argument");
     if (n == 0) return PT_OK;
@@ -1275,11 +1276,11 @@ pt_status pt_kat_arith(pt_device *dev, int op, const float *a, const float *b, f
     if (out1) PT_HIP(hipMemcpy(out1, d1, bytes, hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(d0); (void)hipFree(d1);
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_kat_exhaustive(pt_device *dev, int op, uint32_t first_bits, uint64_t count, uint64_t *n_bad,
                             uint32_t *examples, int max_examples)
-{
+try {
     clear_error();
     if (!dev || !n_bad || op < 0 || op > 4 || max_examples < 0 || (max_examples > 0 && !examples) ||
         count > (1ull << 32))
@@ -1303,10 +1304,10 @@ pt_status pt_kat_exhaustive(pt_device *dev, int op, uint32_t first_bits, uint64_
     (void)hipFree(dbad); (void)hipFree(dex);
     *n_bad = host_bad[0];
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_kat_closest_hit(pt_device *dev, const float *org, const float *dirs, float *t_out, int *face_out, size_t n)
-{
+try {
     clear_error();
     if (!dev || !org || !dirs || !t_out || !face_out) return set_error(PT_ERR_INVALID, "null argument");
     if (!dev->has_scene) return set_error(PT_ERR_NO_SCENE, "no scene uploaded");
@@ -1330,6 +1331,6 @@ pt_status pt_kat_closest_hit(pt_device *dev, const float *org, const float *dirs
     PT_HIP(hipMemcpy(face_out, df, n * 4, hipMemcpyDeviceToHost));
     (void)hipFree(dorg); (void)hipFree(ddir); (void)hipFree(dt); (void)hipFree(df);
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 } // extern "C"

@@ -13,6 +13,9 @@ namespace pt {
 // Thread-local error message behind pt_last_error_string().
 pt_status set_error(pt_status code, const std::string &msg);
 void clear_error();
+// For the function-try-blocks of the C-ABI entry points: turns the exception in flight into a pt_status.
+pt_status exception_status() noexcept;
+#define PT_CATCH_ALL catch (...) { return pt::exception_status(); }
 
 // HostScene.h:55-59 HostScene, owning its storage; exposed through the pt_scene_* C ABI.
 struct HostSceneImpl {

@@ -900,7 +900,7 @@ struct pt_host_scene { HostSceneImpl impl; };
 extern "C" {
 
 pt_status pt_scene_load_glb(const char *path, pt_host_scene **out)
-{
+try {
     clear_error();
     if (!path || !out) return set_error(PT_ERR_INVALID, "null argument");
     std::unique_ptr<pt_host_scene> s(new pt_host_scene());
@@ -908,7 +908,7 @@ pt_status pt_scene_load_glb(const char *path, pt_host_scene **out)
     if (st != PT_OK) return st;
     *out = s.release();
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 /* Legacy-class records derived from the material names of a loaded scene (OBJ + MTL only; all kind 0 for
  * glTF input).  Returns the number of materials; copies up to `cap` records. */
@@ -924,7 +924,7 @@ size_t pt_scene_legacy_materials(const pt_host_scene *scene, pt_legacy_material 
 }
 
 pt_status pt_scene_load_obj(const char *path, pt_host_scene **out)
-{
+try {
     clear_error();
     if (!path || !out) return set_error(PT_ERR_INVALID, "null argument");
     std::unique_ptr<pt_host_scene> s(new pt_host_scene());
@@ -932,12 +932,12 @@ pt_status pt_scene_load_obj(const char *path, pt_host_scene **out)
     if (st != PT_OK) return st;
     *out = s.release();
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_scene_create(const pt_triangle *triangles, size_t n_triangles,
                           const pt_material *materials, size_t n_materials,
                           const pt_texture *textures, size_t n_textures, pt_host_scene **out)
-{
+try {
     clear_error();
     if (!out || (!triangles && n_triangles) || (!materials && n_materials) || (!textures && n_textures))
         return set_error(PT_ERR_INVALID, "null argument");
@@ -956,7 +956,7 @@ pt_status pt_scene_create(const pt_triangle *triangles, size_t n_triangles,
     s->impl.rebuild_texture_views();
     *out = s.release();
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 void pt_scene_free(pt_host_scene *scene) { delete scene; }
 size_t pt_scene_triangle_count(const pt_host_scene *s) { return s ? s->impl.triangles.size() : 0; }
@@ -971,7 +971,7 @@ const char *pt_scene_material_name(const pt_host_scene *s, size_t i)
 }
 
 pt_status pt_scene_apply_cornell_convention(pt_host_scene *scene)
-{
+try {
     clear_error();
     if (!scene) return set_error(PT_ERR_INVALID, "null scene");
     HostSceneImpl &s = scene->impl;
@@ -988,13 +988,13 @@ pt_status pt_scene_apply_cornell_convention(pt_host_scene *scene)
     };
     for (pt_triangle &t : s.triangles) { swap_axes(t.v0); swap_axes(t.v1); swap_axes(t.v2); }
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 // Deterministic terrain: grid x grid cells over [-500,500]^2 (y up), two triangles per cell,
 // height = 40*sin*cos + integer-hash noise; one grey material; a 2-triangle emissive quad
 // above the centre (BASELINE.json config 4).
 pt_status pt_scene_make_terrain(unsigned grid, pt_host_scene **out)
-{
+try {
     clear_error();
     if (!out || grid == 0 || grid > 8192) return set_error(PT_ERR_INVALID, "grid must be in 1..8192");
     std::unique_ptr<pt_host_scene> s(new pt_host_scene());
@@ -1045,10 +1045,10 @@ pt_status pt_scene_make_terrain(unsigned grid, pt_host_scene **out)
     sc.triangles.push_back(l1);
     *out = s.release();
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 pt_status pt_write_ppm(const char *path, int width, int height, const uint8_t *rgb)
-{
+try {
     clear_error();
     if (!path || !rgb || width <= 0 || height <= 0) return set_error(PT_ERR_INVALID, "bad argument");
     FILE *fp = fopen(path, "wb");
@@ -1059,7 +1059,7 @@ pt_status pt_write_ppm(const char *path, int width, int height, const uint8_t *r
     fclose(fp);
     if (w != n) return set_error(PT_ERR_IO, "short write");
     return PT_OK;
-}
+} PT_CATCH_ALL
 
 } // extern "C"
 

@@ -227,7 +227,7 @@ class DevicePathTracer:
 
     def __init__(self, device_idx: int, samplesPerPixel: int, recursionDepth: int, threadBlockSize,
                  hostScene: HostScene, framebuffer: Framebuffer, cameraConfig: CameraConfig,
-                 legacyMaterials=None, spheres=None):
+                 legacyMaterials=None, spheres=None, bvhMode: int = 0):
         self.device_idx_ = device_idx
         self.samplesPerPixel_ = samplesPerPixel
         self.recursionDepth_ = recursionDepth
@@ -241,6 +241,8 @@ class DevicePathTracer:
         capi.check(capi.lib().pt_set_thread_block_size(self._h, *self.threadBlockSize_))
         if legacyMaterials is not None or spheres is not None:      # extension, before the first upload
             self.setLegacyScene(legacyMaterials, spheres, reload=False)
+        if bvhMode:                                                  # opt-in SAH tree, chosen before the one upload
+            self.setBvhMode(bvhMode, reload=False)
         self.reloadWorld()
         self.reloadCamera()
         self.setFramebuffer(framebuffer)

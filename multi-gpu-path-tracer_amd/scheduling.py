@@ -204,9 +204,8 @@ class RenderManager:
         self.device_idx = device_idx
         self.framebuffer_ = Framebuffer(config.resolution, device="cuda:%d" % device_idx)
         self.tracer = DevicePathTracer(device_idx, config.samplesPerPixel, config.recursionDepth,
-                                       config.threadBlockSize, hScene, self.framebuffer_, cameraConfig)
-        if bvh_mode:
-            self.tracer.setBvhMode(bvh_mode)        # opt-in SAH tree (not the reference's traversal)
+                                       config.threadBlockSize, hScene, self.framebuffer_, cameraConfig,
+                                       bvhMode=bvh_mode)        # 1 = opt-in SAH tree (not the reference's traversal)
         n_streams = streams_per_gpu or config.streamsPerGpu
         self.streams = [torch.cuda.Stream(device=device_idx) for _ in range(max(1, n_streams))]
         self._make_tasks()

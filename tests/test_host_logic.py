@@ -113,6 +113,44 @@ def test_bvh_root_leaf_and_tiny_scenes(pt, ob):
     assert c["box_tests"] == 2 * c["segments"]                       # root tested as both of its children
 
 
+def test_threaded_reference_build_equals_the_single_threaded_oracle_build(pt, ob):
+    """The host build forks subtrees of >= 2^16 triangles and costs the split candidates of nodes of >= 2^19
+    triangles concurrently; topology, node numbers and the triangle permutation must be those of the serial
+    build (bvh.h:35-94), which the oracle restates with one thread.  524 290 triangles reach both thresholds."""
+    sc = pt.make_terrain_scene(512)
+    assert len(sc.triangles) >= 1 << 19
+    info, bounds, links, idx = pt.host_bvh_build(sc.triangles)
+    osc = ob.OracleScene(sc.triangles, sc.materials)
+    o_bounds, o_links, o_idx, _ = osc.bvh()
+    assert np.array_equal(links, o_links) and np.array_equal(idx, o_idx)
+    assert np.array_equal(bounds.view(np.uint32), o_bounds.view(np.uint32))
+    info2, bounds2, links2, idx2 = pt.host_bvh_build(sc.triangles)              # and it is deterministic
+    assert info2 == info and np.array_equal(links2, links) and np.array_equal(idx2, idx)
+
+
+@pytest.mark.parametrize("specials", [(np.nan, 0.0, -0.0, 1e-40, -1e-40), (np.nan, np.inf, -np.inf, 3e38, -3e38, 0.0, -0.0)])
+def test_reference_build_handles_nan_zero_and_infinite_coordinates_like_the_oracle(pt, ob, specials):
+    """The host build replaces aabb::extend's fminf / fmaxf by single min / max instructions and evaluates the split
+    candidates from pattern boxes; both rest on 'NaN coordinates are ignored' and 'no bound is a zero'.  Check them
+    on a soup with NaN, signed zeros, denormals (deep tree) and with infinities / huge values (degenerate tree)."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    tris = np.zeros(n, pt.capi.TRIANGLE_DTYPE)
+    for k in ("v0", "v1", "v2"):
+        tris[k]["position"] = rng.normal(0, 50, (n, 3)).astype(np.float32)
+    for _ in range(600):
+        k = ("v0", "v1", "v2")[int(rng.integers(3))]
+        tris[k]["position"][int(rng.integers(n)), int(rng.integers(3))] = specials[int(rng.integers(len(specials)))]
+    tris["v0"]["position"][:200, 0] = 0.0; tris["v1"]["position"][:200, 0] = -0.0
+    mats = np.zeros(1, pt.capi.MATERIAL_DTYPE); mats["emissiveFactor"] = 1
+    mats["baseColorTextureIdx"] = -1; mats["emissiveTextureIdx"] = -1
+    info, bounds, links, idx = pt.host_bvh_build(tris)
+    o_bounds, o_links, o_idx, _ = ob.OracleScene(tris, mats).bvh()
+    assert np.array_equal(links, o_links) and np.array_equal(idx, o_idx)
+    assert np.array_equal(bounds.view(np.uint32), o_bounds.view(np.uint32))
+    assert info["nodes"] > (100 if not np.isinf(specials).any() else 1)
+
+
 def test_fsfl_task_layout_matches_reference_rule(pt):
     """TaskGenerator::generateEqualTasks (TaskGenerator.h:58-80) over getTaskLayout
     (RenderManager.h:42-59): rows of <= maxTasksInRow, last column/row absorb remainders."""
