@@ -402,6 +402,13 @@ def test_capi_argument_checking(pt, box_scene):
     assert lib.pt_host_bvh_build(None, 0, None, None, None, None) == 1
     assert lib.pt_write_ppm(b"/nonexistent-dir/x.ppm", 2, 2, pt.capi.np_ptr(np.zeros(12, np.uint8))) == 5
     assert b"cannot write" in lib.pt_last_error_string()
+    # no C++ exception crosses the C ABI: a triangle count whose working arrays exceed what a vector can hold makes
+    # std::vector throw before anything is read or allocated; it comes back as PT_ERR_NOMEM (9) with a message
+    one = np.zeros(1, pt.capi.TRIANGLE_DTYPE)
+    assert lib.pt_host_bvh_build(pt.capi.np_ptr(one), 1 << 60, None, None, None, None) == 9
+    assert b"allocation failed" in lib.pt_last_error_string()
+    assert lib.pt_host_sah_build(pt.capi.np_ptr(one), 1 << 60, None, None, None) == 9
+    assert pt.capi.STATUS_NAMES[9] == "PT_ERR_NOMEM" and pt.capi.STATUS_NAMES[10] == "PT_ERR_INTERNAL"
     # device entry points with a null device never touch the GPU
     assert lib.pt_device_sync(None) == 1 and lib.pt_counters_reset(None) == 1
     assert lib.pt_render_task_async(None, None, None, 1, 1, None) == 1
