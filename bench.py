@@ -84,7 +84,7 @@ def cpu_baseline(scene, camera, W, H, spp, depth, budget_rows):
     # centred patch one row per thread high, doubled in width up to the full width, then doubled in height up to
     # budget_rows; the first run of >= 5 s (or the biggest allowed) is the one reported.  Short runs are not
     # extrapolated from: the oracle's thread pool takes a few tenths of a second of work to reach its rate.
-    sw, rows = 16, cores
+    sw, rows = 4, cores
     while True:
         ox, oy = (W - sw) // 2, (H - rows) // 2
         t0 = time.perf_counter()
