@@ -24,6 +24,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+# VALU lane-instruction peak: 256 CUs x 4 SIMD-32 x 32 lanes/clk x 2.4 GHz (a wave64 VALU instruction holds its SIMD
+# for 2 cycles, MI355X_MICROARCH.md "Wave scheduling").  Every VALU instruction of these kernels is ONE IEEE op
+# (no FMA contraction by contract), so this is also the op rate.
+VALU_PEAK_LANE_INSTR_S = 256 * 4 * 32 * 2.4e9
+PARITY_NOTE = ("bit-identical (bytes + work counters) to this repo's CPU restatement of the reference integrator; "
+               "parity with the CUDA renderer itself is unpinned (the reference ships no vectors and cannot be built here)")
 
 CONFIGS = {
     # name: (scene, W, H, spp, depth, description)
@@ -44,23 +50,86 @@ def algorithmic_bytes(cnt, pixels):
             + 4.5 * pixels)
 
 
-def measured_traffic(config, workload=None):
-    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes
-    (profiles/*_<config>_pmc_summary.json, FETCH_SIZE / WRITE_SIZE collected in separate passes and
-    corrected as MI355X_MICROARCH.md prescribes); None when no profile of this config AND the same
-    workload string (frame size, spp, depth, tree) is committed."""
+def kernel_build_id():
+    """sha256 (16 hex digits) over the sources every render kernel is compiled from + the compiler flags: a PMC
+    profile only describes the kernels of the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "multi-gpu-path-tracer_amd", "csrc")
+    for name in ("pt_device.hip", "pt_walk.h", "pt_shade.h", "pt_math.h", "pt_kernels.h", "pt_internal.h", "Makefile"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def matching_profile(config, workload, build_id):
+    """The committed rocprofv3 PMC summary (profiles/*_<config>_pmc_summary.json; FETCH_SIZE / WRITE_SIZE / SQ
+    counters collected in separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes) of this exact
+    workload string (scene, frame size, spp, depth, tree).  Returns (summary dict, path, same_build) or
+    (None, None, False).  The work of a frame is deterministic (per-pixel seeds), so the per-launch counts of a
+    profile of the same build hold for every launch of this run; what this run measures itself is the time."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pmc_summary.json" % config)))
-    for path in reversed(files):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pmc_summary.json" % config)), key=os.path.getmtime)
+    best = (None, None, False)
+    for path in files:
         try:
             with open(path) as f:
                 d = json.load(f)
-            if workload is not None and d["bench_line_under_kernel_trace"]["config"]["workload"] != workload:
+            line = d["bench_line_under_kernel_trace"]
+            if line["config"]["workload"] != workload:
                 continue
-            return float(d["hbm_bytes_per_launch"]["total"]), os.path.relpath(path, ROOT), d.get("valu_roofline")
+            same = line.get("kernel_build_id") == build_id
+            if same or best[0] is None or not best[2]:
+                best = (d, os.path.relpath(path, ROOT), same)
         except Exception:
             continue
-    return None, None, None
+    return best
+
+
+def roofline_block(config, workload, cnt, pixels, kernel_ms, launches, kernel_name):
+    """The bound that binds, with the time measured in THIS run (HIP events on the launch stream, pt_kernel_time_read)."""
+    build_id = kernel_build_id()
+    prof, path, same_build = matching_profile(config, workload, build_id)
+    per_launch_s = kernel_ms * 1e-3 / max(launches, 1)
+    alg = algorithmic_bytes(cnt, pixels) / max(launches, 1)
+    hbm_bound = config == "c4"         # the only scene (1 GB) that does not live in the scalar cache / L1 / L2
+    traffic = lane_instr = None
+    if prof is not None:
+        if "hbm_bytes_per_launch" in prof:
+            traffic = float(prof["hbm_bytes_per_launch"]["total"])
+        c = prof.get("counters", {})
+        if "SQ_THREAD_CYCLES_VALU" in c:
+            lane_instr = float(c["SQ_THREAD_CYCLES_VALU"])     # VALU lane-instructions of one launch
+    out = {"bound": "hbm" if hbm_bound else "valu-issue"}
+    if hbm_bound:
+        achieved = traffic / per_launch_s / 1e9 if (traffic and per_launch_s > 0) else None
+        out.update({"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS if achieved is not None else None})
+    else:
+        achieved = lane_instr / per_launch_s if (lane_instr and per_launch_s > 0 and same_build) else None
+        out.update({"achieved": achieved, "peak": VALU_PEAK_LANE_INSTR_S, "unit": "lane-instructions/s",
+                    "frac": achieved / VALU_PEAK_LANE_INSTR_S if achieved is not None else None})
+    out.update({
+        "traffic": traffic,
+        "source": ("per-launch counts (HBM bytes = FETCH_SIZE x2 + WRITE_SIZE; VALU lane-instructions = SQ_THREAD_CYCLES_VALU) "
+                   "from %s, %s; kernel time measured in this run with HIP events on the launch stream"
+                   % (path, "taken on this build of the kernels" if same_build else
+                      "taken on ANOTHER build of the kernels (VALU figure withheld, HBM bytes indicative)"))
+                  if prof is not None else "no committed PMC profile of this workload: only the time is measured",
+        "kernel_build_id": build_id,
+        "kernel": kernel_name, "kernel_ms_avg": kernel_ms / max(launches, 1), "launches": launches,
+        # SURVEY 8(d)'s byte model, kept as a secondary figure: on the KB-sized Cornell scenes these bytes are served by
+        # SGPRs / the scalar cache / LDS, never by HBM, so they are NOT divided by the HBM peak
+        "algorithmic_hbm_equiv": {
+            "bytes_per_launch": alg, "bytes_per_segment": alg * max(launches, 1) / max(cnt["segments"], 1),
+            "GB_per_s": alg / per_launch_s / 1e9 if per_launch_s > 0 else None,
+            "note": "32*n_box + 40*n_tri + 40*n_light + 64*segments + 4.5 B/pixel from the kernel's own counters; an "
+                    "operand-delivery rate (registers/caches), not HBM traffic"},
+        "note": ROOFLINE_NOTES.get(config, ROOFLINE_NOTES["c2"]),
+    })
+    if hbm_bound and lane_instr and same_build and per_launch_s > 0:
+        out["valu_issue_frac"] = lane_instr / per_launch_s / VALU_PEAK_LANE_INSTR_S
+    return out
 
 
 def load_scene(pt, kind):
@@ -76,7 +145,11 @@ def cpu_baseline(scene, camera, W, H, spp, depth, budget_rows):
     """The oracle (CPU restatement of the reference integrator) timed on this host's cores on
     a bounded sample of the SAME workload: a centred strip (or, for very dear scenes, patch) of the frame."""
     from oracle import binding as ob
-    cores = min(os.cpu_count() or 1, 16)
+    host_cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))      # the cores this process may actually use (a GPU box gives a share)
+    except Exception:
+        cores = host_cores
     osc = ob.OracleScene(scene.triangles, scene.materials, scene.textures)
     cam = (camera[0], camera[1], 45.0, 45.0)
     # The sample grows until it is long enough to be a fair timing and then stops, whatever the scene costs per
@@ -99,20 +172,19 @@ def cpu_baseline(scene, camera, W, H, spp, depth, budget_rows):
         else:
             break
     return {
-        "value": cnt["segments"] / dt, "unit": "ray-segments/s", "cores": cores, "kind": "port",
+        "value": cnt["segments"] / dt, "unit": "ray-segments/s", "cores": cores, "host_cpu_count": host_cores, "kind": "port",
         "sample": "task %dx%d at offset (%d, %d) of the %dx%d frame (%.3g%% of pixels), %d spp, %d bounces, %.1f s"
                   % (sw, rows, ox, oy, W, H, 100.0 * sw * rows / (W * H), spp, depth, dt),
     }
 
 
 ROOFLINE_NOTES = {
-    "c2": "algorithmic bytes (SURVEY 8d) are served by the scalar cache / L1 on this KB-sized scene; "
-          "the HBM traffic of a launch is `traffic` bytes, the kernel is VALU-issue bound (DESIGN.md 4)",
-    "c3": "algorithmic bytes (SURVEY 8d) are served by L1/L2 (0.7 MB of tree + 3 MB texture); the HBM traffic of "
-          "a launch is `traffic` bytes; the SAH kernel is issue/divergence bound (DESIGN.md 4)",
-    "c4": "1 GB scene: `traffic` (PMC FETCH_SIZE x2 + WRITE_SIZE) is what leaves the L2s (Infinity-Cache hits are "
-          "counted in it, MI355X_MICROARCH.md); the SAH kernel is memory-latency bound here (one dependent node or "
-          "triangle fetch per micro-step, DESIGN.md 4)",
+    "c2": "2.4 KB scene held in SGPRs / the scalar cache: the kernel is bound by VALU issue (every op a single IEEE "
+          "instruction); `traffic` = HBM bytes of a launch (framebuffer + spills), a rounding error against 8 TB/s",
+    "c3": "0.7 MB tree + 3 MB texture live in L1/L2: bound by VALU issue / divergence; `traffic` = HBM bytes of a launch",
+    "c4": "1 GB scene: `traffic` (PMC FETCH_SIZE x2 + WRITE_SIZE, an upper bound) is what leaves the L2s (Infinity-Cache "
+          "hits are counted in it, MI355X_MICROARCH.md); the walk is bound by dependent-fetch latency, not bandwidth "
+          "(DESIGN.md 4b), so frac is low by construction",
 }
 ROOFLINE_NOTES["c1"] = ROOFLINE_NOTES["c5"] = ROOFLINE_NOTES["c2"]
 
@@ -125,6 +197,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-visible", action="store_true", help="skip the extra frames timed with the D2H copy of the frame")
     ap.add_argument("--tile-schedule", type=int, default=1, choices=[0, 1],
                     help="0: tiles in raster order; 1: ordered by their cost in the previous frame (pt_set_tile_schedule)")
     ap.add_argument("--cpu-rows", type=int, default=360)
@@ -236,24 +309,42 @@ def main():
         total = {k: int(v) for k, v in zip(keys, tot.tolist())}
     else:
         total = cnt
+    if world > 1:
+        # the launch that bounds the frame is the slowest rank's; bytes and pixels are the whole frame's
+        kmax = torch.tensor([kernel_ms], dtype=torch.float64, device=rdev)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        kernel_ms = float(kmax.item())
+
+    # SURVEY 8(d) defines the frame as "incl. gather to host-visible RGB": the boundary hands over DEVICE buffers
+    # (`value` above), so the host-visible variant -- every frame followed by the D2H copy of RGB + YUV into pinned
+    # host memory on rank 0 -- is timed separately and reported beside it.
+    host_visible_ms = None
+    if not args.no_host_visible:
+        fb = mgr.getFramebuffer()
+        pin_rgb = torch.empty(fb.rgb.numel(), dtype=torch.uint8).pin_memory() if rank == 0 else None
+        pin_yuv = torch.empty(fb.yuv.numel(), dtype=torch.uint8).pin_memory() if rank == 0 else None
+        n_hv = max(1, min(args.steps, 5))
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n_hv):
+            mgr.renderFrame()
+            if rank == 0:
+                pin_rgb.copy_(fb.rgb); pin_yuv.copy_(fb.yuv)
+        sync_all()
+        host_visible_ms = (time.perf_counter() - t0) * 1e3 / n_hv
 
     if rank == 0:
         if args.ppm:
             pt.write_ppm(args.ppm, mgr.getCurrentFrame())
         seg_per_s = total["segments"] / elapsed
-        # roofline of the dominant (only) kernel, from rank 0's own launches
-        my_pixels = sum(t.width * t.height for t in mgr.renderTasks_) * args.steps
-        bytes_rank0 = algorithmic_bytes(cnt, my_pixels)
-        achieved = bytes_rank0 / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic, traffic_src, valu = (None, None, None)
-        if world == 1:                                   # matched on the workload string (size, spp, depth, tree)
-            traffic, traffic_src, valu = measured_traffic(args.config, desc)
+        # roofline of the dominant (only) kernel: one launch per rank and frame
         out = {
             "metric": "ray-segments/s", "value": seg_per_s, "unit": "ray-segments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "scene": kind, "width": W, "height": H, "spp": spp, "bounces": depth,
+                       "parity": PARITY_NOTE,
                        "tile_schedule": "cost order from the previous frame" if args.tile_schedule else "raster order",
                        "parallelism": "row-bands x%d (band_rows=%d), scene replicated, gather to rank 0"
                                       % (world, args.band_rows)},
@@ -261,17 +352,14 @@ def main():
             "scene_upload_s": upload_s,
             "segments_per_path": total["segments"] / max(total["paths"], 1),
             "tests_per_segment": {k: total[k] / max(total["segments"], 1) for k in ("box_tests", "tri_tests", "light_tests")},
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": bytes_rank0 / max(launches, 1),
-                "valu_roofline_from_profile": valu,
-                "note": ROOFLINE_NOTES.get(args.config, ROOFLINE_NOTES["c2"]),
-                "kernel": "pt::dev::render_kernel", "kernel_ms_avg": kernel_ms / max(launches, 1),
-                "launches": launches,
-                "algorithmic_bytes_per_segment": bytes_rank0 / max(cnt["segments"], 1),
-            },
+            "kernel_build_id": kernel_build_id(),
+            # N > 1: whole-frame counters over the slowest rank's kernel time (per-launch profile counts are those of a
+            # whole-frame launch and do not apply to a 1/N share, so `achieved` stays null there)
+            "roofline": roofline_block(args.config, desc if world == 1 else desc + " [1/%d shares]" % world, total,
+                                       W * H * args.steps, kernel_ms, launches, mgr.tracer.kernelName()),
         }
+        if host_visible_ms is not None:
+            out["ms_per_step_host_visible"] = host_visible_ms
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, camera, W, H, spp, depth, args.cpu_rows)
         print(json.dumps(out), flush=True)

@@ -179,6 +179,9 @@ PT_API pt_status pt_debug_counters_read(pt_device *dev, uint64_t out8[8]);
  * measured with HIP events on the launch stream; n_launches may be NULL.                */
 PT_API pt_status pt_kernel_time_read(pt_device *dev, double *ms_total, uint64_t *n_launches);
 PT_API pt_status pt_kernel_time_reset(pt_device *dev);
+/* Name of the gfx950 kernel the latest render launch of this device ran (the symbol a rocprofv3 kernel trace
+ * shows), e.g. "pt::dev::render_kernel<false, true, 1>"; empty before the first launch.          */
+PT_API pt_status pt_kernel_name_read(pt_device *dev, char *out, size_t cap);
 
 /* BVH introspection (known-answer tests against the oracle).  bounds: 6 floats per node
  * {x.min,x.max,y.min,y.max,z.min,z.max}; links: 4 u32 per node {left,right,firstTri,triCount}

@@ -89,6 +89,7 @@ _PROTOS = {
     "pt_debug_counters_read": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "pt_kernel_time_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "pt_kernel_time_reset": (C.c_int, [_vp]),
+    "pt_kernel_name_read": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "pt_bvh_info_read": (C.c_int, [_vp, C.POINTER(BvhInfo)]),
     "pt_bvh_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "pt_host_bvh_build": (C.c_int, [_vp, C.c_size_t, C.POINTER(BvhInfo), _vp, _vp, _vp]),

@@ -14,6 +14,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
         stamp_trips++;
 #endif
         if (kLegacy) spheres_hit(P, L.ro, L.rd, 0.001f, h);
+        if (kWalk == 0 || kWalk == 3) fold_counters(L, P.fold_bits);      // per-lane walks count in 32 bits per lane
         shade<kLegacy>(L, P, V, h);
     }
 
@@ -203,8 +205,16 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
     if (in_frame && P.depth == 0) L.n_paths = (uint32_t)P.spp;      // camera rays are generated, then ray_color returns untraced
     bool walking = false;
     uint32_t cost = 0;                                    // wave-uniform: micro-step trips + 8 per outer trip
+    // Wave totals taken out of the per-lane 32-bit test counters before any of them can wrap (this loop's top is a
+    // convergent point; a lane adds at most one segment's tests between two visits).  Kept wave-uniform, in SGPRs.
+    unsigned long long spill_box = 0, spill_tri = 0;
     while (true) {
         cost += 8;
+        if (__any(((L.n_box | L.n_tri) >> P.fold_bits) != 0)) {
+            spill_box = uniform64(spill_box + wave_sum64(L.n_box));
+            spill_tri = uniform64(spill_tri + wave_sum64(L.n_tri));
+            L.n_box = 0; L.n_tri = 0;
+        }
         if (alive && !walking) {
             if (L.need_new && !start_path(L, P, x, y)) {
                 alive = false;
@@ -233,7 +243,7 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
         if (alive && !walking) shade(L, P, V, W.h);
     }
     if (in_frame) write_pixel(P, L.col, pixel_index);
-    flush_counters(P, L, lane);
+    flush_counters(P, L, lane, spill_box, spill_tri);
     record_tile_cost(P, tid, cost);
 }
 
@@ -363,6 +373,19 @@ using namespace pt;
                                              ":" + std::to_string(__LINE__) + " '" #call "'");   \
     } while (0)
 
+// Temporary device allocations of one C-ABI call: freed on every return path, PT_HIP's early returns included.
+struct DevBufs {
+    std::vector<void *> ptrs;
+    ~DevBufs() { for (void *p : ptrs) (void)hipFree(p); }
+    hipError_t alloc(void **out, size_t bytes)
+    {
+        hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+        if (e == hipSuccess) ptrs.push_back(*out);
+        return e;
+    }
+    void release() { ptrs.clear(); }          // ownership passes to the caller
+};
+
 // Adaptive tile schedule of one task geometry (pt_set_tile_schedule): the render kernel records what
 // every 8x8 tile cost, a device radix sort turns that into next launch's wave-slot -> tile order
 // (dearest first), so the launch ends on cheap tiles instead of on a straggler that started last.
@@ -377,6 +400,7 @@ struct TileSchedule {
     hipEvent_t last_use = nullptr;
     hipStream_t last_stream = nullptr;
     bool used = false;
+    int busy = 0;                 // launches that hold this entry outside dev->mu (between choosing it and recording last_use)
     uint64_t stamp = 0;
 };
 
@@ -403,6 +427,7 @@ struct pt_device {
     bool sah = false;             // uploaded with the opt-in SAH tree instead of the reference topology
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
     int spec_pct = 50;            // ... and leaves the walk loop when <= this % of the walkers remain
+    int fold_bits = 31;           // per-lane test counters fold at 2^fold_bits (PTAMD_FOLD_BITS lowers it: tests of the folding)
     int bvh_mode = 0;             // pt_set_bvh_mode: applies to the next pt_upload_scene
     int force_walk = -1;          // pt_set_traversal_mode: -1 auto, else the requested schedule
     int queue_entries = 8;        // per-lane leaf queue capacity (phase A -> phase B)
@@ -418,6 +443,8 @@ struct pt_device {
     bool legacy_on = false;       // the uploaded scene uses a legacy material or a sphere
     int coop_mode = -1;           // cooperative kernel: -1 auto (stack walk, big leaf, small launch), 0 off, 1 on
     int max_waves = 8192;         // wave slots of the device: CUs x 4 SIMDs x 8
+    size_t lds_limit = 64 * 1024; // LDS one workgroup may ask for (hipDeviceProp_t::maxSharedMemoryPerMultiProcessor)
+    std::vector<std::pair<const void *, size_t>> lds_raised;   // kernels whose dynamic-LDS cap was raised, and to what
     // adaptive tile schedule
     int tile_schedule = 1;        // 0 raster order, 1 cost-ordered from the previous launch of the same task
     std::vector<TileSchedule *> schedules;
@@ -427,6 +454,7 @@ struct pt_device {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_events;
     double ms_total = 0.0;
     uint64_t launches = 0;
+    const char *last_kernel = "";  // what the latest render launch ran (pt_kernel_name_read)
 };
 
 // Traversal schedule for the uploaded tree.  The wave-uniform walks cost the UNION of the 64
@@ -511,11 +539,13 @@ try {
     // out-of-range values are ignored
     if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;
     if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 100) d->spec_pct = v; }
+    if (const char *e = getenv("PTAMD_FOLD_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 31) d->fold_bits = v; }
     if (const char *e = getenv("PTAMD_COOP")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->coop_mode = v; }
     {
         hipDeviceProp_t prop;
         PT_HIP(hipGetDeviceProperties(&prop, device_index));
         d->max_waves = std::max(1, prop.multiProcessorCount) * 4 * 8;
+        d->lds_limit = std::max<size_t>((size_t)64 * 1024, std::max((size_t)prop.sharedMemPerBlock, (size_t)prop.maxSharedMemoryPerMultiProcessor));
     }
     PT_HIP(hipMalloc((void **)&d->d_counters, 8 * sizeof(unsigned long long)));
     PT_HIP(hipMemset(d->d_counters, 0, 8 * sizeof(unsigned long long)));
@@ -885,6 +915,7 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.queue_entries = dev->queue_entries;
     P.sah = dev->sah ? 1 : 0;
     P.spec_pct = dev->spec_pct;
+    P.fold_bits = dev->fold_bits;
     P.tile_order = nullptr; P.tile_cost = nullptr;
     P.legacy_mats = dev->d_legacy; P.spheres = dev->d_spheres; P.n_spheres = dev->n_spheres;
     if (dev->sah) P.stack_entries = (int)dev->sah_stack;
@@ -908,7 +939,10 @@ static TileSchedule *schedule_for(pt_device *dev, const RenderParams &P, unsigne
         size_t victim = dev->schedules.size();
         for (size_t i = 0; i < dev->schedules.size(); i++) {
             TileSchedule *t = dev->schedules[i];
-            const bool idle = !t->used || hipEventQuery(t->last_use) == hipSuccess;
+            // busy: some launch is between picking this entry and recording last_use -- never evictable, whatever
+            // the event says (an event that was never recorded, or whose previous record has completed, also
+            // queries as hipSuccess)
+            const bool idle = t->busy == 0 && (!t->used || hipEventQuery(t->last_use) == hipSuccess);
             if (idle && (victim == dev->schedules.size() || t->stamp < dev->schedules[victim]->stamp)) victim = i;
         }
         (void)hipGetLastError();
@@ -939,6 +973,43 @@ static TileSchedule *schedule_for(pt_device *dev, const RenderParams &P, unsigne
     return t.release();
 }
 
+// The kernel a launch of the uploaded scene runs, and whether it is the cooperative (4 waves per tile) form.
+typedef void (*RenderKernel)(RenderParams);
+struct KernelChoice { RenderKernel fn; const char *name; };
+#define PT_KERNEL(...) KernelChoice{__VA_ARGS__, "pt::dev::" #__VA_ARGS__}
+static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool stage, bool packed)
+{
+    if (walk == 3 && dev->sah_persistent) {
+        const size_t scene_bytes = dev->n_pairs * sizeof(NodePair) + dev->n_tris * sizeof(TriIsect);
+        return scene_bytes <= ((size_t)64 << 20) ? PT_KERNEL(dev::render_kernel_sah6) : PT_KERNEL(dev::render_kernel_sah);
+    }
+    if (walk == 3) return PT_KERNEL(dev::render_kernel<false, true, 3>);
+    if (walk == 1) return PT_KERNEL(dev::render_kernel<false, true, 1>);
+    if (coop) return PT_KERNEL(dev::render_kernel_coop);
+    if (walk == 2) return PT_KERNEL(dev::render_kernel<false, true, 2>);
+    if (dev->legacy_on) return PT_KERNEL(dev::render_kernel<false, false, 0, true>);
+    if (stage) return packed ? PT_KERNEL(dev::render_kernel<true, true, 0>) : PT_KERNEL(dev::render_kernel<true, false, 0>);
+    return packed ? PT_KERNEL(dev::render_kernel<false, true, 0>) : PT_KERNEL(dev::render_kernel<false, false, 0>);
+}
+#undef PT_KERNEL
+
+// Dynamic LDS of a launch against what the device gives one workgroup.  Above the 64 KB every HIP kernel may
+// use by default the limit has to be raised per kernel; above the hardware's (160 KB on gfx950) the launch
+// would fail with an opaque HIP error, so it is refused here with the reason (a per-lane stack of `max_stack`
+// entries for 256 lanes plus the per-lane leaf queue: reference trees deeper than ~40 levels in the per-lane walk).
+static pt_status ensure_lds(pt_device *dev, const void *kern, size_t lds)
+{
+    if (lds <= (size_t)64 * 1024) return PT_OK;
+    if (lds > dev->lds_limit)
+        return set_error(PT_ERR_UNSUPPORTED, "this tree needs " + std::to_string(lds) + " B of LDS per workgroup (per-lane traversal stacks of " +
+                                                 std::to_string(dev->bvh.max_stack) + " entries), the device offers " + std::to_string(dev->lds_limit));
+    std::lock_guard<std::mutex> lk(dev->mu);
+    for (auto &kv : dev->lds_raised) if (kv.first == kern && kv.second >= lds) return PT_OK;
+    PT_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dev->lds_raised.push_back({kern, lds});
+    return PT_OK;
+}
+
 static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream)
 {
     long long tiles = (long long)P.tiles_x * P.tiles_y;
@@ -955,49 +1026,77 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
                       (dev->coop_mode == 1 || (dev->coop_mode < 0 && dev->bvh.max_leaf >= 64 &&
                                                tiles * dev::kWavesPerBlock <= 3ll * dev->max_waves));
     if (coop) { blocks = (unsigned)tiles; P.queue_entries = 10; P.queue_dwords = 1; }   // LDS per thread: 2 x (float4 partial hit + visit rank)
-    size_t lds = lds_bytes(P, dev::kBlock, stage);
+    const size_t lds = lds_bytes(P, dev::kBlock, stage);
+    const KernelChoice choice = pick_kernel(dev, walk, coop, stage, packed);
+    const RenderKernel kern = choice.fn;
+    {
+        const pt_status st = ensure_lds(dev, (const void *)kern, lds);
+        if (st != PT_OK) return st;
+    }
     hipStream_t hs = (hipStream_t)stream;
-    std::pair<hipEvent_t, hipEvent_t> ev;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     TileSchedule *sched = nullptr;
     P.tile_order = nullptr; P.tile_cost = nullptr;
+    // An error between here and the bookkeeping at the end gives the event pair back and releases the schedule.
+    auto fail = [&](pt_status st) {
+        std::lock_guard<std::mutex> lk(dev->mu);
+        if (ev.first && ev.second) dev->free_events.push_back(ev);
+        else { if (ev.first) (void)hipEventDestroy(ev.first); if (ev.second) (void)hipEventDestroy(ev.second); }
+        if (sched) sched->busy--;
+        return st;
+    };
+#define PT_HIP_LAUNCH(call)                                                                                \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(set_error(PT_ERR_HIP, std::string("HIP ERROR = ") + std::to_string((int)e_) + " (" + \
+                                                  hipGetErrorString(e_) + ") at " + __FILE__ + ":" +       \
+                                                  std::to_string(__LINE__) + " '" #call "'"));             \
+    } while (0)
     {
         std::lock_guard<std::mutex> lk(dev->mu);
         if (!dev->free_events.empty()) { ev = dev->free_events.back(); dev->free_events.pop_back(); }
-        else { PT_HIP(hipEventCreate(&ev.first)); PT_HIP(hipEventCreate(&ev.second)); }
+        else {
+            hipError_t e1 = hipEventCreate(&ev.first), e2 = e1 == hipSuccess ? hipEventCreate(&ev.second) : e1;
+            if (e2 != hipSuccess) {
+                if (ev.first) (void)hipEventDestroy(ev.first);
+                return set_error(PT_ERR_HIP, std::string("HIP ERROR = ") + std::to_string((int)e2) + " (" + hipGetErrorString(e2) + ") creating a timing event");
+            }
+        }
         // one wave slot per tile; tiny launches are not worth a sort
         if (dev->tile_schedule == 1 && blocks >= 64) sched = schedule_for(dev, P, coop ? blocks : blocks * dev::kWavesPerBlock, hs);
         if (sched) {
+            // Pinned while this launch uses it outside the lock (its sort and its last_use record below): eviction
+            // in schedule_for() skips busy entries, so another thread's launch can never free it under our feet.
+            sched->busy++;
             // a schedule is read and rewritten by its launches: order them across streams
-            if (sched->used && sched->last_stream != hs) PT_HIP(hipStreamWaitEvent(hs, sched->last_use, 0));
+            if (sched->used && sched->last_stream != hs) {
+                hipError_t e = hipStreamWaitEvent(hs, sched->last_use, 0);
+                if (e != hipSuccess) {
+                    sched->busy--; sched = nullptr;
+                    dev->free_events.push_back(ev);
+                    return set_error(PT_ERR_HIP, std::string("HIP ERROR = ") + std::to_string((int)e) + " (" + hipGetErrorString(e) + ") in hipStreamWaitEvent");
+                }
+            }
             sched->used = true; sched->last_stream = hs;
             P.tile_order = sched->order; P.tile_cost = sched->cost;
         }
     }
-    PT_HIP(hipEventRecord(ev.first, hs));
-    if (walk == 3 && dev->sah_persistent) {
-        const size_t scene_bytes = dev->n_pairs * sizeof(NodePair) + dev->n_tris * sizeof(TriIsect);
-        if (scene_bytes <= ((size_t)64 << 20)) hipLaunchKernelGGL(dev::render_kernel_sah6, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-        else hipLaunchKernelGGL(dev::render_kernel_sah, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    }
-    else if (walk == 3) hipLaunchKernelGGL((dev::render_kernel<false, true, 3>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else if (walk == 1) hipLaunchKernelGGL((dev::render_kernel<false, true, 1>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else if (coop) hipLaunchKernelGGL(dev::render_kernel_coop, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else if (walk == 2) hipLaunchKernelGGL((dev::render_kernel<false, true, 2>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else if (dev->legacy_on) hipLaunchKernelGGL((dev::render_kernel<false, false, 0, true>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else if (stage && packed) hipLaunchKernelGGL((dev::render_kernel<true, true, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else if (stage) hipLaunchKernelGGL((dev::render_kernel<true, false, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else if (packed) hipLaunchKernelGGL((dev::render_kernel<false, true, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    else hipLaunchKernelGGL((dev::render_kernel<false, false, 0>), dim3(blocks), dim3(dev::kBlock), lds, hs, P);
-    PT_HIP(hipGetLastError());
-    PT_HIP(hipEventRecord(ev.second, hs));
+    PT_HIP_LAUNCH(hipEventRecord(ev.first, hs));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
+    PT_HIP_LAUNCH(hipGetLastError());
+    PT_HIP_LAUNCH(hipEventRecord(ev.second, hs));
     if (sched) {
         // next launch's order: tiles by this launch's cost, dearest first (stable, so ties keep raster order)
-        PT_HIP(hipcub::DeviceRadixSort::SortPairsDescending(sched->temp, sched->temp_bytes, sched->cost, sched->sorted_cost,
-                                                            sched->iota, sched->order, (int)sched->slots, 0, 32, hs));
-        PT_HIP(hipEventRecord(sched->last_use, hs));
+        PT_HIP_LAUNCH(hipcub::DeviceRadixSort::SortPairsDescending(sched->temp, sched->temp_bytes, sched->cost, sched->sorted_cost,
+                                                                   sched->iota, sched->order, (int)sched->slots, 0, 32, hs));
+        PT_HIP_LAUNCH(hipEventRecord(sched->last_use, hs));
     }
+#undef PT_HIP_LAUNCH
     {
         std::lock_guard<std::mutex> lk(dev->mu);
+        if (sched) sched->busy--;                // last_use is recorded: from here on hipEventQuery(last_use) tells when it is idle
+        dev->last_kernel = choice.name;
         dev->pending.push_back(ev);
         // keep the event pool bounded when nobody reads the timings: fold finished launches in
         if (dev->pending.size() > 64) {
@@ -1151,6 +1250,15 @@ try {
     return PT_OK;
 } PT_CATCH_ALL
 
+pt_status pt_kernel_name_read(pt_device *dev, char *out, size_t cap)
+try {
+    clear_error();
+    if (!dev || !out || cap == 0) return set_error(PT_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(dev->mu);
+    snprintf(out, cap, "%s", dev->last_kernel);
+    return PT_OK;
+} PT_CATCH_ALL
+
 pt_status pt_kernel_time_reset(pt_device *dev)
 try {
     clear_error();
@@ -1195,10 +1303,14 @@ try {
     if (!dev || width <= 0 || height <= 0 || !rgb || !yuv) return set_error(PT_ERR_INVALID, "bad argument");
     PT_HIP(hipSetDevice(dev->index));
     size_t total = (size_t)width * (size_t)height;
-    PT_HIP(hipMalloc((void **)rgb, total * 3));
-    PT_HIP(hipMalloc((void **)yuv, total + 2 * (total / 4)));
-    PT_HIP(hipMemset(*rgb, 0, total * 3));
-    PT_HIP(hipMemset(*yuv, 0, total + 2 * (total / 4)));
+    DevBufs bufs;                                  // a failure after the first hipMalloc frees it again
+    uint8_t *r = nullptr, *y = nullptr;
+    PT_HIP(bufs.alloc((void **)&r, total * 3));
+    PT_HIP(bufs.alloc((void **)&y, total + 2 * (total / 4)));
+    PT_HIP(hipMemset(r, 0, total * 3));
+    PT_HIP(hipMemset(y, 0, total + 2 * (total / 4)));
+    bufs.release();
+    *rgb = r; *yuv = y;
     return PT_OK;
 } PT_CATCH_ALL
 
@@ -1264,8 +1376,9 @@ try {
     PT_HIP(hipSetDevice(dev->index));
     float *da = nullptr, *db = nullptr, *d0 = nullptr, *d1 = nullptr;
     size_t bytes = n * sizeof(float);
-    PT_HIP(hipMalloc((void **)&da, bytes)); PT_HIP(hipMalloc((void **)&db, bytes));
-    PT_HIP(hipMalloc((void **)&d0, bytes)); PT_HIP(hipMalloc((void **)&d1, bytes));
+    DevBufs bufs;
+    PT_HIP(bufs.alloc((void **)&da, bytes)); PT_HIP(bufs.alloc((void **)&db, bytes));
+    PT_HIP(bufs.alloc((void **)&d0, bytes)); PT_HIP(bufs.alloc((void **)&d1, bytes));
     PT_HIP(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
     if (b) PT_HIP(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice)); else PT_HIP(hipMemset(db, 0, bytes));
     unsigned blocks = (unsigned)((n + 255) / 256);
@@ -1274,7 +1387,6 @@ try {
     PT_HIP(hipDeviceSynchronize());
     PT_HIP(hipMemcpy(out0, d0, bytes, hipMemcpyDeviceToHost));
     if (out1) PT_HIP(hipMemcpy(out1, d1, bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(d0); (void)hipFree(d1);
     return PT_OK;
 } PT_CATCH_ALL
 
@@ -1289,8 +1401,9 @@ try {
     if (count == 0) return PT_OK;
     PT_HIP(hipSetDevice(dev->index));
     unsigned long long *dbad = nullptr; uint32_t *dex = nullptr;
-    PT_HIP(hipMalloc((void **)&dbad, 16));
-    PT_HIP(hipMalloc((void **)&dex, sizeof(uint32_t) * (size_t)(max_examples > 0 ? max_examples : 1)));
+    DevBufs bufs;
+    PT_HIP(bufs.alloc((void **)&dbad, 16));
+    PT_HIP(bufs.alloc((void **)&dex, sizeof(uint32_t) * (size_t)(max_examples > 0 ? max_examples : 1)));
     PT_HIP(hipMemset(dbad, 0, 16));
     PT_HIP(hipMemset(dex, 0, sizeof(uint32_t) * (size_t)(max_examples > 0 ? max_examples : 1)));
     uint64_t want_blocks = (count + 255) / 256;
@@ -1301,7 +1414,6 @@ try {
     unsigned long long host_bad[2] = {0, 0};
     PT_HIP(hipMemcpy(host_bad, dbad, 16, hipMemcpyDeviceToHost));
     if (max_examples > 0) PT_HIP(hipMemcpy(examples, dex, sizeof(uint32_t) * (size_t)max_examples, hipMemcpyDeviceToHost));
-    (void)hipFree(dbad); (void)hipFree(dex);
     *n_bad = host_bad[0];
     return PT_OK;
 } PT_CATCH_ALL
@@ -1317,19 +1429,23 @@ try {
     memset(&P, 0, sizeof P);
     fill_params(dev, P);
     float *dorg = nullptr, *ddir = nullptr, *dt = nullptr; int *df = nullptr;
-    PT_HIP(hipMalloc((void **)&dorg, n * 12)); PT_HIP(hipMalloc((void **)&ddir, n * 12));
-    PT_HIP(hipMalloc((void **)&dt, n * 4)); PT_HIP(hipMalloc((void **)&df, n * 4));
+    DevBufs bufs;
+    PT_HIP(bufs.alloc((void **)&dorg, n * 12)); PT_HIP(bufs.alloc((void **)&ddir, n * 12));
+    PT_HIP(bufs.alloc((void **)&dt, n * 4)); PT_HIP(bufs.alloc((void **)&df, n * 4));
     PT_HIP(hipMemcpy(dorg, org, n * 12, hipMemcpyHostToDevice));
     PT_HIP(hipMemcpy(ddir, dirs, n * 12, hipMemcpyHostToDevice));
     unsigned blocks = (unsigned)((n + 255) / 256);
     P.queue_dwords = 2; P.shade_lds = 0;
     size_t lds = lds_bytes(P, 256, false);
+    {
+        const pt_status st = ensure_lds(dev, (const void *)dev::kat_hit_kernel, lds);
+        if (st != PT_OK) return st;
+    }
     hipLaunchKernelGGL(dev::kat_hit_kernel, dim3(blocks), dim3(256), lds, 0, P, dorg, ddir, dt, df, n);
     PT_HIP(hipGetLastError());
     PT_HIP(hipDeviceSynchronize());
     PT_HIP(hipMemcpy(t_out, dt, n * 4, hipMemcpyDeviceToHost));
     PT_HIP(hipMemcpy(face_out, df, n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(dorg); (void)hipFree(ddir); (void)hipFree(dt); (void)hipFree(df);
     return PT_OK;
 } PT_CATCH_ALL
 

@@ -45,6 +45,7 @@ struct RenderParams {
     int spec_pct;                     // SAH kernel: leave the walk loop when <= this % of the walkers remain
     int sah;                          // 1: nodes/tris hold the opt-in SAH tree (traverse_sah)
     int shade_lds;                    // 1: shade / material / light tables are staged in LDS
+    int fold_bits;                    // per-lane 32-bit test counters are folded into wider ones at 2^fold_bits (31; tests lower it)
 };
 
 CameraBasis camera_basis(const pt_camera &cfg);

@@ -51,6 +51,13 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
     return v;
 }
 
+// A value every lane already agrees on, moved to SGPRs (the compiler cannot prove a shuffle reduction uniform).
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ __forceinline__ unsigned long long wave_max64(unsigned long long v)
 {
     for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
@@ -146,7 +153,17 @@ struct PathState {
     unsigned bounce;       // segments traced on the current path
     bool need_new;         // the next trip starts a new sample
     uint32_t n_paths, n_seg, n_box, n_tri, n_light;
+    // per-lane walks only: how many times 2^fold_bits were taken out of n_box / n_tri.  A lane's tests grow as
+    // spp x depth x tests per segment (reference tree on the 8 M-triangle terrain: 2.5e6 per segment), which
+    // passes 2^32 at C5-class sample counts; the wave-uniform walks keep 64-bit wave totals instead.
+    uint32_t box_hi, tri_hi;
 };
+
+__device__ __forceinline__ void fold_counters(PathState &L, int bits)
+{
+    if (L.n_box >> bits) { L.n_box -= 1u << bits; L.box_hi++; }
+    if (L.n_tri >> bits) { L.n_tri -= 1u << bits; L.tri_hi++; }
+}
 
 __device__ __forceinline__ void path_init(PathState &L, const RenderParams &P, int pixel_index)
 {
@@ -156,6 +173,7 @@ __device__ __forceinline__ void path_init(PathState &L, const RenderParams &P, i
     L.ro = P.cam.origin; L.rd = mk3(0.0f, 0.0f, 0.0f);
     L.s = 0; L.bounce = 0; L.need_new = true;
     L.n_paths = L.n_seg = L.n_box = L.n_tri = L.n_light = 0;
+    L.box_hi = L.tri_hi = 0;
 }
 
 // Starts the next sample of pixel (x, y): DevicePathTracer.h:84-86 + camera::get_ray camera.h:95-97.
@@ -431,7 +449,9 @@ __device__ __forceinline__ void flush_counters(const RenderParams &P, const Path
                                                unsigned long long wave_box = 0, unsigned long long wave_tri = 0)
 {
     const uint32_t c0 = wave_sum(L.n_paths), c1 = wave_sum(L.n_seg), c4 = wave_sum(L.n_light);
-    const unsigned long long c2 = wave_sum64(L.n_box) + wave_max64(wave_box), c3 = wave_sum64(L.n_tri) + wave_max64(wave_tri);
+    const unsigned long long lane_box = (unsigned long long)L.n_box + ((unsigned long long)L.box_hi << P.fold_bits);
+    const unsigned long long lane_tri = (unsigned long long)L.n_tri + ((unsigned long long)L.tri_hi << P.fold_bits);
+    const unsigned long long c2 = wave_sum64(lane_box) + wave_max64(wave_box), c3 = wave_sum64(lane_tri) + wave_max64(wave_tri);
     if (lane == 0 && ((c0 | c1 | c4) != 0 || (c2 | c3) != 0)) {
         atomicAdd(&P.counters[0], (unsigned long long)c0);
         atomicAdd(&P.counters[1], (unsigned long long)c1);

@@ -351,6 +351,12 @@ class DevicePathTracer:
         capi.check(capi.lib().pt_kernel_time_read(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def kernelName(self) -> str:
+        """Symbol of the kernel the latest render launch ran (what a rocprofv3 kernel trace shows)."""
+        buf = C.create_string_buffer(256)
+        capi.check(capi.lib().pt_kernel_name_read(self._h, buf, len(buf)))
+        return buf.value.decode()
+
     def resetKernelTime(self):
         capi.check(capi.lib().pt_kernel_time_reset(self._h))
 

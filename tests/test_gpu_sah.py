@@ -1,7 +1,9 @@
 """Opt-in SAH acceleration structure.  It is NOT the reference's traversal: the
-set of triangles a ray tests differs, so bit-equality with the oracle is not guaranteed for
-ill-conditioned rays.  These tests measure how close it is: closest hits on random rays, whole
-images, and the work it saves."""
+set of triangles a ray tests differs, so bit-equality with the oracle is not guaranteed by
+construction for ill-conditioned rays.  On every committed seed, scene and frame below the measured
+difference is ZERO, and that is what the tests assert (round 1 tolerated up to 0.5 % and never saw a
+difference; a regression that flips a handful of pixels must fail).  No grazing-ray exception is
+known; if one ever shows up it gets its own documented, printed allowance here."""
 import numpy as np
 import pytest
 
@@ -44,7 +46,7 @@ def test_sah_closest_hits_equal_reference_traversal(pt, box_scene, duck_scene, g
     ref_tr.close()
     sah_tr.close()
     print("%s: %d / %d rays differ" % (name, mismatch, n))
-    assert mismatch <= n // 20000          # <= 0.005 %: only grazing-ray artefacts may differ
+    assert mismatch == 0                   # measured: 0 of 1e7 on both scenes (strict t < t_max, first visited wins, triangle.h:100)
     assert hits > n // 2
 
 
@@ -58,11 +60,13 @@ def test_sah_images_match_oracle(pt, box_scene, duck_scene, gpu_device, name, W,
     tr.resetCounters()
     tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0))
     tr.waitForRenderTask()
-    rgb, cnt = fb.rgb_host(), tr.readCounters()
+    rgb, yuv, cnt = fb.rgb_host(), fb.yuv_host(), tr.readCounters()
     tr.close()
     diff = (rgb != g["rgb"])
     print("%s: %d of %d bytes differ; tri tests %d -> %d per frame" % (name, int(diff.sum()), diff.size, int(g["counters"][3]), cnt["tri_tests"]))
-    assert diff.mean() < 2e-3              # a handful of samples may take another path
+    assert int(diff.sum()) == 0            # golden = the oracle's (reference traversal) bytes
+    assert np.array_equal(yuv, g["yuv"])
+    assert cnt["segments"] == int(g["counters"][1]) and cnt["light_tests"] == int(g["counters"][4])
     assert cnt["paths"] == int(g["counters"][0])
     assert cnt["tri_tests"] < int(g["counters"][3])        # and it is less work
     if name == "duck":
@@ -76,7 +80,7 @@ def test_sah_handles_tiny_and_terrain_scenes(pt, ob, gpu_device):
     ref = osc.render(cam, 64, 36, 2, 6, threads=8)
     tr, fb = _tracer(pt, terr, cam, 64, 36, 2, 6, sah=True)
     tr.renderTaskAsync(pt.RenderTask(64, 36, 0, 0)); tr.waitForRenderTask()
-    assert (fb.rgb_host() != ref[0]).mean() < 5e-3
+    assert np.array_equal(fb.rgb_host(), ref[0]) and np.array_equal(fb.yuv_host(), ref[1])
     tr.close()
     # three triangles: the SAH "tree" is a single pair with an empty right child
     tris = np.zeros(3, pt.capi.TRIANGLE_DTYPE)
@@ -93,21 +97,26 @@ def test_sah_handles_tiny_and_terrain_scenes(pt, ob, gpu_device):
     tr.close()
 
 
-@pytest.mark.parametrize("name,W,H,spp", [("box", 480, 270, 64), ("duck", 320, 180, 32), ("box", 1920, 1080, 256)])
+@pytest.mark.parametrize("name,W,H,spp", [("box", 480, 270, 64), ("duck", 320, 180, 32), ("box", 1920, 1080, 256),
+                                          ("duck", 1920, 1080, 256)])
 def test_sah_vs_reference_tree_at_scale(pt, box_scene, duck_scene, gpu_device, name, W, H, spp):
     """Frames too big for the CPU oracle: render the same frame through the reference-topology walk
-    (bit-exact with the oracle by test_gpu_parity) and through the SAH tree, count differing bytes."""
+    (bit-exact with the oracle by test_gpu_parity) and through the SAH tree; bytes (RGB and YUV) and the
+    segment / path / light-test counts must be equal.  The last case is BASELINE.json configs[2] (C3) at
+    full size: ~6 s of GPU for the reference tree's 2 120 triangle tests per segment."""
     scene, cam = (box_scene, BOX_CAMERA) if name == "box" else (duck_scene, DUCK_CAMERA)
     ref_tr, ref_fb = _tracer(pt, scene, cam, W, H, spp, 8, sah=False)
     ref_tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); ref_tr.waitForRenderTask()
-    ref = ref_fb.rgb_host().copy(); ref_cnt = ref_tr.readCounters(); ref_tr.close()
+    ref = ref_fb.rgb_host().copy(); ref_yuv = ref_fb.yuv_host().copy(); ref_cnt = ref_tr.readCounters(); ref_tr.close()
     sah_tr, sah_fb = _tracer(pt, scene, cam, W, H, spp, 8, sah=True)
     sah_tr.resetCounters()
     sah_tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); sah_tr.waitForRenderTask()
-    got = sah_fb.rgb_host().copy(); cnt = sah_tr.readCounters(); sah_tr.close()
+    got = sah_fb.rgb_host().copy(); got_yuv = sah_fb.yuv_host().copy(); cnt = sah_tr.readCounters(); sah_tr.close()
     ndiff = int((got != ref).sum())
     maxdiff = int(np.abs(got.astype(int) - ref.astype(int)).max())
     print("%s %dx%d %dspp: %d of %d bytes differ (max |delta| %d); segments %d vs %d; tri tests %.3g -> %.3g"
           % (name, W, H, spp, ndiff, got.size, maxdiff, cnt["segments"], ref_cnt["segments"], ref_cnt["tri_tests"], cnt["tri_tests"]))
-    assert ndiff <= got.size * 1e-4
-    assert abs(cnt["segments"] - ref_cnt["segments"]) <= ref_cnt["segments"] * 1e-5
+    assert ndiff == 0 and np.array_equal(got_yuv, ref_yuv)
+    for k in ("paths", "segments", "light_tests"):
+        assert cnt[k] == ref_cnt[k], (k, cnt[k], ref_cnt[k])
+    assert cnt["tri_tests"] < ref_cnt["tri_tests"]
