@@ -426,3 +426,31 @@ def test_pure_legacy_scene_with_spheres_matches_the_oracle(pt, ob, gpu_device):
     with pytest.raises(pt.capi.PtError):
         tr.setTraversalMode(2)
     tr.close()
+
+
+def test_per_lane_test_counters_fold_before_they_can_wrap(pt, ob, duck_scene, duck_oracle, gpu_device, monkeypatch):
+    """The per-lane walks count box / triangle tests in 32-bit per-lane registers; spp x depth x tests per segment
+    passes 2^32 at C5-class sample counts on big reference trees, so the kernels fold them into wider counters at
+    2^31.  Here the fold point is lowered to 2^10 (PTAMD_FOLD_BITS, read at pt_device_create), which makes every
+    lane fold hundreds of times in a small frame: the totals must still be the oracle's, in the per-lane walk of
+    the reference tree (per-lane high words) and in the SAH kernel (wave-uniform spill words)."""
+    monkeypatch.setenv("PTAMD_FOLD_BITS", "10")
+    W, H, spp, depth = 64, 36, 2, 4
+    ref = duck_oracle.render(DUCK_CAMERA, W, H, spp, depth, threads=8)
+    assert ref[2]["tri_tests"] > (W * H) << 12                      # every lane passes the fold point many times
+    _assert_same(_render_gpu(pt, duck_scene, DUCK_CAMERA, W, H, spp, depth, mode=1), ref)
+    terr = pt.make_terrain_scene(48)
+    cam = ((0.0, 220.0, 620.0), (0.0, -0.35, -1.0), 45.0, 45.0)
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    plain = pt.DevicePathTracer(0, 64, 8, (8, 8), terr, fb, pt.CameraConfig(*cam), bvhMode=1)
+    monkeypatch.delenv("PTAMD_FOLD_BITS")
+    fb2 = pt.Framebuffer(pt.Resolution(W, H))
+    wide = pt.DevicePathTracer(0, 64, 8, (8, 8), terr, fb2, pt.CameraConfig(*cam), bvhMode=1)
+    got = []
+    for tr in (plain, wide):
+        tr.resetCounters()
+        tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+        got.append(tr.readCounters())
+        tr.close()
+    assert got[0] == got[1] and got[0]["box_tests"] > (W * H) << 11
+    assert np.array_equal(fb.rgb_host(), fb2.rgb_host())
