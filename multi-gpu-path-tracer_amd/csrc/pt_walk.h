@@ -252,6 +252,133 @@ __device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 
     return h;
 }
 
+// ---- wave-uniform mask walk with DEALT sparse leaves (kWalk 4) ----------------------------------------------
+// The mask walk above runs a leaf's triangle tests for the whole wave as soon as ONE lane's ray hit the leaf's
+// (origin-containing) box: on the Cornell box three leaves are hit by ~90 % of the rays, the other eight by 15-50 %,
+// so half of the wave sits idle through most leaf loops (PMC: 56 % VALU lane utilisation).  Here the box walk is the
+// same, but a leaf that fewer than `deal_min` lanes hit is not tested in place: every (ray, triangle) pair it asks
+// for becomes an ITEM in a per-wave LDS list, and after the walk the wave works the list off 64 items at a time,
+// each lane testing whatever (ray, triangle) its item names -- ray and triangle records come from LDS, the closest
+// hit of a ray is merged with one ds_min_u64 on the key (t bits, visit rank, slot).  min over (t, rank) is exactly
+// what the reference's in-order `t < ray_t.max` update computes (triangle.h:100: strict, so the first visited of
+// equal t wins), whatever order the tests run in.  Leaves most lanes hit (and any leaf whose items would not fit)
+// keep the in-place loop with scalar operands.  Per ray the SET of slab and triangle tests is bvh.h:178-246's, and the
+// counters count them per ray as before.
+struct DealView {
+    uint16_t *items;                 // this wave's item list: lane | slot << 6
+    float4 *ray_a;                   // this wave's 64 x {o.x, o.y, o.z, d.x}
+    float2 *ray_b;                   // this wave's 64 x {d.y, d.z}
+    unsigned long long *keys;        // this wave's 64 closest-hit keys: t bits << 32 | rank << 16 | slot
+    const float4 *tris;              // the workgroup's LDS copy of the TriIsect table (3 x float4 per slot)
+    int cap;                         // item list capacity
+    int deal_min;                    // a leaf hit by at least this many lanes is tested in place
+    int recompute_uv;                // the scene has textures: barycentrics of a dealt winner are needed
+};
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // cross-lane hand-off inside ONE wave: the LDS serves a wave's requests in order, so only the compiler needs telling
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Called by ALL 64 lanes of the wave (lanes without a ray pass live = false): the rounds that work the item list off
+// use every lane, whether or not its own pixel still has samples to trace.
+__device__ __forceinline__ Hit traverse_uniform_dealt(const RenderParams &P, const DealView &D, int lane, bool live, v3 o, v3 d, float tmin,
+                                                      float tmax0, unsigned long long &n_box, unsigned long long &n_tri)
+{
+    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+    uint32_t best_rank = 0;
+    float tmax = tmax0;
+    const v3 inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
+    const ConstF4 nodes = as_constant(P.nodes);
+    const ConstF4 tris = as_constant(P.tris);
+    D.ray_a[lane] = make_float4(o.x, o.y, o.z, d.x);
+    D.ray_b[lane] = make_float2(d.y, d.z);
+    D.keys[lane] = ~0ull;
+    uint32_t n_items = 0;                                // wave-uniform
+    unsigned long long act = live ? 1ull : 0ull;
+    const int n_pairs = P.n_pairs;
+    for (int p = 0; p < n_pairs; p++) {
+        const bool on = (act >> p) & 1ull;
+        const unsigned long long on_mask = __ballot(on);
+        if (on_mask == 0ull) continue;
+        const float4 a = nodes[4 * p], b = nodes[4 * p + 1], c = nodes[4 * p + 2], lf = nodes[4 * p + 3];
+        const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
+        const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
+        const bool hl = on && box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
+        const bool hr = on && box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
+        n_box += 2u * (uint32_t)__popcll(on_mask);
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const bool hit = side ? hr : hl;
+            const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
+            if (cnt == 0) {
+                if (hit) act |= 1ull << link;
+            } else if (const unsigned long long hit_mask = __ballot(hit)) {
+                const uint32_t lanes = (uint32_t)__popcll(hit_mask);
+                n_tri += (unsigned long long)cnt * lanes;
+                const uint32_t need = cnt * lanes;
+                if ((int)lanes < D.deal_min && n_items + need <= (uint32_t)D.cap && link + cnt <= 1024u) {
+                    // sparse leaf: its (ray, triangle) pairs go on the list, triangle-major so that a round's lanes read
+                    // one or two triangle records (LDS broadcast) and ascending ray records
+                    if (hit) {
+                        const uint32_t pos = n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit_mask, 0u));
+                        for (uint32_t k = 0; k < cnt; k++) D.items[pos + k * lanes] = (uint16_t)((uint32_t)lane | ((link + k) << 6));
+                    }
+                    n_items += need;
+                } else {
+                    for (uint32_t k = link; k < link + cnt; k++) {
+                        const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
+                        const float e2z = tris.scalar(3 * k + 2, 0);
+                        const uint32_t krank = __float_as_uint(tris.scalar(3 * k + 2, 1));
+                        if (hit) {
+                            float t, u, v;
+                            if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
+                                tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k; best_rank = krank;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (n_items == 0) return h;                          // wave-uniform
+    wave_lds_fence();
+    for (uint32_t j0 = 0; j0 < n_items; j0 += kWave) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        if (j < n_items) {
+            const uint32_t it = D.items[j];
+            const uint32_t r = it & 63u, k = it >> 6;
+            const float4 ra = D.ray_a[r];
+            const float2 rb = D.ray_b[r];
+            const float4 ta = D.tris[3 * k], tb = D.tris[3 * k + 1];
+            const float2 tc = reinterpret_cast<const float2 *>(D.tris + 3 * k + 2)[0];
+            float t, u, v;
+            const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x),
+                                    mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), t, u, v);
+            if (ok & (t < tmax0) & (t > tmin))           // triangle.h:98 with the segment's initial interval
+                atomicMin(&D.keys[r], ((unsigned long long)__float_as_uint(t) << 32) | ((unsigned long long)__float_as_uint(tc.y) << 16) | k);
+        }
+    }
+    wave_lds_fence();
+    const unsigned long long key = D.keys[lane];
+    const unsigned long long mine = h.slot >= 0 ? (((unsigned long long)__float_as_uint(h.t) << 32) | ((unsigned long long)best_rank << 16) | (uint32_t)h.slot)
+                                                : ~0ull;
+    if (key < mine) {                                    // a dealt triangle is closer (or as close and visited earlier)
+        h.t = __uint_as_float((uint32_t)(key >> 32));
+        h.slot = (int)(key & 0xffffu);
+        if (D.recompute_uv) {
+            const float4 ta = D.tris[3 * h.slot], tb = D.tris[3 * h.slot + 1];
+            const float e2z = reinterpret_cast<const float *>(D.tris + 3 * h.slot + 2)[0];
+            float t;
+            (void)mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, t, h.u, h.v);
+        }
+    }
+    return h;
+}
+
 // The same wave-uniform walk for bigger trees (cornell_duck: 332 inner nodes, leaves of up to
 // 1603 triangles): instead of a 64-bit mask each lane keeps the NEXT pair on its path plus its
 // pending right siblings on the per-lane LDS stack.  Pairs are numbered in visit order, so the
