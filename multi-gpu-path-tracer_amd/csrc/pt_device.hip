@@ -108,6 +108,79 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
     record_tile_cost(P, tid, wave_max(L.n_seg));      // trips of this wave's loop = segments of its busiest lane
 }
 
+// Mask walk with dealt sparse leaves (kWalk 4, traverse_uniform_dealt): same integrator, but the rounds that work the
+// item list off use all 64 lanes, so the wave loop is convergent (every lane stays until the wave's last pixel is done)
+// and lanes without a ray of their own pass live = false.
+#ifndef PT_DEAL_WAVES
+#define PT_DEAL_WAVES 7
+#endif
+#ifdef PT_TIMELINE
+// diagnostic build only (tools/timeline.sh): per wave {start, end} of the 100 MHz real-time counter, hardware id and tile,
+// for an occupancy-over-time picture of one launch; never compiled into the shipped library
+__device__ uint32_t g_timeline[4 * 131072];
+#endif
+
+template <bool kInPlace>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_WAVES, PT_DEAL_WAVES))) void render_kernel_dealt(RenderParams P)
+{
+    extern __shared__ float4 lds_raw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+#ifdef PT_TIMELINE
+    const uint32_t tl_start = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
+    int x, y, pixel_index;
+    const bool in_frame = lane_pixel(P, tid, x, y, pixel_index);
+    const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
+    const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
+    const DealView D = deal_carve(P, V.end, tid, kBlock);
+    PathState L;
+    path_init(L, P, pixel_index);
+    bool alive = in_frame && P.depth > 0;
+    if (in_frame && P.depth == 0) L.n_paths = (uint32_t)P.spp;
+    unsigned long long wave_box = 0, wave_tri = 0;
+    // Issue priority by remaining work (P.lrpt).  The SIMD arbitrates VALU issue by priority, then AGE: left alone, the
+    // oldest wave of a SIMD runs almost unimpeded and the youngest starves, so when the launch's queue runs dry a SIMD
+    // works its last waves off one after the other and ends on a lone wave at half the issue rate.  A wave that still
+    // has most of its samples ahead outranks one that is nearly done: the waves of a SIMD then finish together.
+    int prio_now = 0;
+    while (true) {
+        const unsigned long long alive_mask = __ballot(alive);
+        if (alive_mask == 0ull) break;
+        if (P.lrpt) {
+            const int s_now = __builtin_amdgcn_readlane(L.s, (int)__builtin_ctzll(alive_mask));     // a tile's pixels progress within a few %
+            const int left4 = (P.spp - s_now) * 4;
+            const int want = left4 > 3 * P.spp ? 3 : left4 > 2 * P.spp ? 2 : left4 > P.spp ? 1 : 0;
+            if (want != prio_now) {
+                prio_now = want;
+                if (want == 3) __builtin_amdgcn_s_setprio(3);
+                else if (want == 2) __builtin_amdgcn_s_setprio(2);
+                else if (want == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        bool trace = alive;
+        if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
+        if (trace) L.n_seg++;
+        const Hit h = traverse_uniform_dealt<kInPlace>(P, D, lane, trace, L.ro, L.rd, 0.001f, 3.402823466e+38f, wave_box, wave_tri);
+        if (trace) shade(L, P, V, h);
+    }
+    if (in_frame) write_pixel(P, L.col, pixel_index);
+    flush_counters(P, L, lane, wave_box, wave_tri);
+    record_tile_cost(P, tid, wave_max(L.n_seg));
+#ifdef PT_TIMELINE
+    {
+        const uint32_t slot = blockIdx.x * kWavesPerBlock + tid / kWave;
+        if (lane == 0 && slot < 131072u) {
+            g_timeline[4 * slot] = tl_start;
+            g_timeline[4 * slot + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            g_timeline[4 * slot + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));                       // HW_ID
+            g_timeline[4 * slot + 3] = (wave_max(L.n_seg) & 0xffffu) | (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16);   // cost | XCC_ID << 16
+        }
+    }
+#endif
+}
+
 // Cooperative kernel for reference trees with big leaves (cornell_duck: one leaf of 1603 triangles, 2 120
 // triangle tests per ray segment).  The four waves of a workgroup render the SAME 8x8 tile: each holds
 // the full path state of its 64 pixels and does the box walk and the shading redundantly (bit-identical,
@@ -427,6 +500,10 @@ struct pt_device {
     bool sah = false;             // uploaded with the opt-in SAH tree instead of the reference topology
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
     int spec_pct = 50;            // ... and leaves the walk loop when <= this % of the walkers remain
+    int deal_cap = 768, deal_min = 48;   // dealt walk (kWalk 4): item list capacity per wave; in-place threshold (lanes)
+    int lrpt = 0;                 // dealt kernel: issue priority by remaining samples (PTAMD_LRPT)
+    bool deal_auto = true;        // automatic choice prefers the dealt walk over the plain mask walk (PTAMD_DEAL=0: off)
+    bool any_tex = false;
     int fold_bits = 31;           // per-lane test counters fold at 2^fold_bits (PTAMD_FOLD_BITS lowers it: tests of the folding)
     int bvh_mode = 0;             // pt_set_bvh_mode: applies to the next pt_upload_scene
     int force_walk = -1;          // pt_set_traversal_mode: -1 auto, else the requested schedule
@@ -463,12 +540,14 @@ struct pt_device {
 static int choose_walk(const pt_device *d)
 {
     const bool mask_ok = d->n_pairs <= 64, stack_ok = d->n_pairs <= 4096;
+    const bool deal_ok = mask_ok && d->n_tris <= 1024;         // item = lane | slot << 6 in 16 bits
     if (d->legacy_on) return d->force_walk <= 0 ? 0 : -1;      // the extension is compiled into the per-lane walk only
     if (d->sah) return 3;                     // the SAH tree has its own walk
     if (d->force_walk == 0) return 0;
     if (d->force_walk == 1) return mask_ok ? 1 : -1;
     if (d->force_walk == 2) return stack_ok ? 2 : -1;
-    return mask_ok ? 1 : (stack_ok ? 2 : 0);
+    if (d->force_walk == 4) return deal_ok ? 4 : -1;
+    return deal_ok && d->deal_auto ? 4 : (mask_ok ? 1 : (stack_ok ? 2 : 0));
 }
 
 // `hs` != null: stream-ordered free (the schedule's last launch has finished); null: plain free after
@@ -539,6 +618,10 @@ try {
     // out-of-range values are ignored
     if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;
     if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 100) d->spec_pct = v; }
+    if (const char *e = getenv("PTAMD_DEAL")) d->deal_auto = atoi(e) != 0;
+    if (const char *e = getenv("PTAMD_LRPT")) d->lrpt = atoi(e) != 0;
+    if (const char *e = getenv("PTAMD_DEAL_MIN")) { const int v = atoi(e); if (v >= 0 && v <= 65) d->deal_min = v; }
+    if (const char *e = getenv("PTAMD_DEAL_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 8192) d->deal_cap = v & ~7; }
     if (const char *e = getenv("PTAMD_FOLD_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 31) d->fold_bits = v; }
     if (const char *e = getenv("PTAMD_COOP")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->coop_mode = v; }
     {
@@ -784,6 +867,8 @@ try {
         dev->n_spheres = (int)dev->spheres_next.size();
     }
     dev->legacy_on = legacy_on;
+    dev->any_tex = false;
+    for (const MatRec &r : mrec) dev->any_tex = dev->any_tex || r.baseTex >= 0 || r.emisTex >= 0;
     dev->bvh = std::move(bvh);
     dev->light_faces = lights;
     dev->n_lights = (int)lights.size();
@@ -867,14 +952,14 @@ try {
 pt_status pt_set_traversal_mode(pt_device *dev, int mode)
 try {
     clear_error();
-    if (!dev || mode < 0 || mode > 3) return set_error(PT_ERR_INVALID, "mode must be 0 (auto), 1 (per-lane), 2 (wave-uniform, mask) or 3 (wave-uniform, stack)");
+    if (!dev || mode < 0 || mode > 4) return set_error(PT_ERR_INVALID, "mode must be 0 (auto), 1 (per-lane), 2 (wave-uniform, mask), 3 (wave-uniform, stack) or 4 (mask walk with dealt leaves)");
     const int saved = dev->force_walk;
-    dev->force_walk = mode - 1;                 // -1 auto, 0 per-lane, 1 mask, 2 stack
+    dev->force_walk = mode == 4 ? 4 : mode - 1;  // -1 auto, 0 per-lane, 1 mask, 2 stack, 4 mask + dealt leaves
     if (dev->has_scene) {
         int w = choose_walk(dev);
         if (w < 0) {
             dev->force_walk = saved;
-            return set_error(PT_ERR_UNSUPPORTED, "this tree is too big for the requested wave-uniform walk (mask: <= 64 inner nodes, stack: <= 4096)");
+            return set_error(PT_ERR_UNSUPPORTED, "this tree is too big for the requested wave-uniform walk (mask: <= 64 inner nodes; dealt: also <= 1024 triangles; stack: <= 4096)");
         }
         dev->walk = w;
     }
@@ -897,6 +982,8 @@ static size_t lds_bytes(const RenderParams &P, int block, bool stage)
     f4 += ((size_t)P.stack_entries * block + 3) / 4;
     f4 += ((size_t)P.queue_entries * block * P.queue_dwords + 3) / 4;
     if (P.shade_lds) f4 += (size_t)P.n_tris * 3 + (size_t)P.n_mats * 3 + (size_t)P.n_lights * 5;
+    if (P.deal_cap > 0)       // dev::deal_carve
+        f4 += (size_t)P.n_tris * 3 + (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 2 + 15) / 16);
     return f4 * 16;
 }
 
@@ -916,6 +1003,7 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.sah = dev->sah ? 1 : 0;
     P.spec_pct = dev->spec_pct;
     P.fold_bits = dev->fold_bits;
+    P.deal_cap = 0; P.deal_min = dev->deal_min; P.any_tex = dev->any_tex ? 1 : 0; P.lrpt = dev->lrpt;
     P.tile_order = nullptr; P.tile_cost = nullptr;
     P.legacy_mats = dev->d_legacy; P.spheres = dev->d_spheres; P.n_spheres = dev->n_spheres;
     if (dev->sah) P.stack_entries = (int)dev->sah_stack;
@@ -976,7 +1064,7 @@ static TileSchedule *schedule_for(pt_device *dev, const RenderParams &P, unsigne
 // The kernel a launch of the uploaded scene runs, and whether it is the cooperative (4 waves per tile) form.
 typedef void (*RenderKernel)(RenderParams);
 struct KernelChoice { RenderKernel fn; const char *name; };
-#define PT_KERNEL(...) KernelChoice{__VA_ARGS__, "pt::dev::" #__VA_ARGS__}
+#define PT_KERNEL(...) KernelChoice{__VA_ARGS__, "pt::" #__VA_ARGS__}
 static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool stage, bool packed)
 {
     if (walk == 3 && dev->sah_persistent) {
@@ -985,6 +1073,7 @@ static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool 
     }
     if (walk == 3) return PT_KERNEL(dev::render_kernel<false, true, 3>);
     if (walk == 1) return PT_KERNEL(dev::render_kernel<false, true, 1>);
+    if (walk == 4) return dev->deal_min > 64 ? PT_KERNEL(dev::render_kernel_dealt<false>) : PT_KERNEL(dev::render_kernel_dealt<true>);
     if (coop) return PT_KERNEL(dev::render_kernel_coop);
     if (walk == 2) return PT_KERNEL(dev::render_kernel<false, true, 2>);
     if (dev->legacy_on) return PT_KERNEL(dev::render_kernel<false, false, 0, true>);
@@ -1017,7 +1106,8 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     const int walk = dev->walk;
     const bool stage = dev->lds_scene && walk == 0 && !dev->legacy_on, packed = dev->packed_queue && !dev->legacy_on;
     if (walk != 0) P.queue_entries = 0;
-    if (walk == 1) P.stack_entries = 0;
+    if (walk == 1 || walk == 4) P.stack_entries = 0;
+    P.deal_cap = walk == 4 ? dev->deal_cap : 0;
     // big leaves + stack walk: four waves per tile, each testing a quarter of every leaf (render_kernel_coop)
     // It pays when the launch is small for the machine (a rank's share of a multi-GPU frame): measured on
     // the duck, 1/6 of a 1080p frame and less gains (1/8: 1.85 -> 1.09 s), 1/4 and more loses (whole frame
@@ -1258,6 +1348,17 @@ try {
     snprintf(out, cap, "%s", dev->last_kernel);
     return PT_OK;
 } PT_CATCH_ALL
+
+#ifdef PT_TIMELINE
+PT_API pt_status pt_debug_timeline_read(pt_device *dev, uint32_t *out, size_t n_words)
+try {
+    clear_error();
+    if (!dev || !out || n_words > 4 * 131072) return set_error(PT_ERR_INVALID, "bad argument");
+    PT_HIP(hipSetDevice(dev->index));
+    PT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(dev::g_timeline), n_words * 4));
+    return PT_OK;
+} PT_CATCH_ALL
+#endif
 
 pt_status pt_kernel_time_reset(pt_device *dev)
 try {

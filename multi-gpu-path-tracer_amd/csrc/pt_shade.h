@@ -119,6 +119,7 @@ struct ShadeView {
     const float4 *shade;      // 3 x float4 per slot
     const float4 *mats;       // 3 x float4 per material
     const float4 *lights;     // 5 x float4 per light
+    float4 *end;              // first float4 of the workgroup's LDS after the staged tables
 };
 
 __device__ __forceinline__ ShadeView stage_shade(const RenderParams &P, float4 *lds, int tid, int block)
@@ -134,12 +135,37 @@ __device__ __forceinline__ ShadeView stage_shade(const RenderParams &P, float4 *
         for (int i = tid; i < nl; i += block) lds[ns + nm + i] = gl[i];
         __syncthreads();
         V.shade = lds; V.mats = lds + ns; V.lights = lds + ns + nm;
+        V.end = lds + ns + nm + nl;
     } else {
+        V.end = lds;
         V.shade = reinterpret_cast<const float4 *>(P.shade);
         V.mats = reinterpret_cast<const float4 *>(P.mats);
         V.lights = reinterpret_cast<const float4 *>(P.lights);
     }
     return V;
+}
+
+// LDS of the dealt walk (kWalk 4, pt_walk.h): the workgroup's copy of the TriIsect table, then per wave
+// {64 x float4 ray_a, 64 x u64 keys, 64 x float2 ray_b, deal_cap x u16 items}.  Mirrored by lds_bytes() on the host.
+__device__ __forceinline__ DealView deal_carve(const RenderParams &P, float4 *lds, int tid, int block)
+{
+    DealView D;
+    const float4 *gt = reinterpret_cast<const float4 *>(P.tris);
+    const int nt = P.n_tris * 3;
+    for (int i = tid; i < nt; i += block) lds[i] = gt[i];
+    __syncthreads();
+    D.tris = lds;
+    const int wave = tid / kWave;
+    const size_t per_wave_f4 = (size_t)kWave + kWave / 2 + kWave / 2 + ((size_t)P.deal_cap * 2 + 15) / 16;
+    float4 *w = lds + nt + (size_t)wave * per_wave_f4;
+    D.ray_a = w;
+    D.keys = reinterpret_cast<unsigned long long *>(w + kWave);
+    D.ray_b = reinterpret_cast<float2 *>(w + kWave + kWave / 2);
+    D.items = reinterpret_cast<uint16_t *>(w + kWave + kWave);
+    D.cap = P.deal_cap;
+    D.deal_min = P.deal_min;
+    D.recompute_uv = P.any_tex;
+    return D;
 }
 
 // render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and

@@ -11,7 +11,10 @@ namespace pt {
 namespace dev {
 
 constexpr int kWave = 64;
-constexpr int kWavesPerBlock = 4;
+#ifndef PT_WAVES_PER_BLOCK
+#define PT_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = PT_WAVES_PER_BLOCK;
 constexpr int kBlock = kWave * kWavesPerBlock;
 
 struct Hit {
@@ -283,8 +286,33 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One pass over the wave's item list: 64 items at a time, each lane testing the (ray, triangle) pair its item names.
+__device__ __forceinline__ void deal_rounds(const DealView &D, int lane, uint32_t n_items, float tmin, float tmax0)
+{
+    wave_lds_fence();
+    for (uint32_t j0 = 0; j0 < n_items; j0 += kWave) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        if (j < n_items) {
+            const uint32_t it = D.items[j];
+            const uint32_t r = it & 63u, k = it >> 6;
+            const float4 ra = D.ray_a[r];
+            const float2 rb = D.ray_b[r];
+            const float4 ta = D.tris[3 * k], tb = D.tris[3 * k + 1];
+            const float2 tc = reinterpret_cast<const float2 *>(D.tris + 3 * k + 2)[0];
+            float t, u, v;
+            const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x),
+                                    mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), t, u, v);
+            if (ok & (t < tmax0) & (t > tmin))           // triangle.h:98 with the segment's initial interval
+                atomicMin(&D.keys[r], ((unsigned long long)__float_as_uint(t) << 32) | ((unsigned long long)__float_as_uint(tc.y) << 16) | k);
+        }
+    }
+    wave_lds_fence();
+}
+
 // Called by ALL 64 lanes of the wave (lanes without a ray pass live = false): the rounds that work the item list off
 // use every lane, whether or not its own pixel still has samples to trace.
+// kInPlace = false: every leaf is dealt (a list that fills up is worked off and reused), no in-place loop is compiled.
+template <bool kInPlace>
 __device__ __forceinline__ Hit traverse_uniform_dealt(const RenderParams &P, const DealView &D, int lane, bool live, v3 o, v3 d, float tmin,
                                                       float tmax0, unsigned long long &n_box, unsigned long long &n_tri)
 {
@@ -298,6 +326,7 @@ __device__ __forceinline__ Hit traverse_uniform_dealt(const RenderParams &P, con
     D.ray_b[lane] = make_float2(d.y, d.z);
     D.keys[lane] = ~0ull;
     uint32_t n_items = 0;                                // wave-uniform
+    bool any_items = false;                              // wave-uniform: some test of this segment went through the list
     unsigned long long act = live ? 1ull : 0ull;
     const int n_pairs = P.n_pairs;
     for (int p = 0; p < n_pairs; p++) {
@@ -319,15 +348,31 @@ __device__ __forceinline__ Hit traverse_uniform_dealt(const RenderParams &P, con
             } else if (const unsigned long long hit_mask = __ballot(hit)) {
                 const uint32_t lanes = (uint32_t)__popcll(hit_mask);
                 n_tri += (unsigned long long)cnt * lanes;
-                const uint32_t need = cnt * lanes;
-                if ((int)lanes < D.deal_min && n_items + need <= (uint32_t)D.cap && link + cnt <= 1024u) {
+                if (!kInPlace) {
+                    const uint32_t rank_in = __builtin_amdgcn_mbcnt_hi((uint32_t)(hit_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit_mask, 0u));
+                    // every leaf is dealt; a list that cannot take another triangle's pairs is worked off first
+                    any_items = true;
+                    uint32_t k0 = 0;
+                    while (k0 < cnt) {
+                        const uint32_t room = ((uint32_t)D.cap - n_items) / lanes;
+                        if (room == 0) { deal_rounds(D, lane, n_items, tmin, tmax0); n_items = 0; continue; }
+                        const uint32_t take = cnt - k0 < room ? cnt - k0 : room;
+                        if (hit) {
+                            const uint32_t pos = n_items + rank_in;
+                            for (uint32_t k = 0; k < take; k++) D.items[pos + k * lanes] = (uint16_t)((uint32_t)lane | ((link + k0 + k) << 6));
+                        }
+                        n_items += take * lanes;
+                        k0 += take;
+                    }
+                } else if ((int)lanes < D.deal_min && n_items + cnt * lanes <= (uint32_t)D.cap) {
                     // sparse leaf: its (ray, triangle) pairs go on the list, triangle-major so that a round's lanes read
                     // one or two triangle records (LDS broadcast) and ascending ray records
+                    any_items = true;
                     if (hit) {
                         const uint32_t pos = n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit_mask, 0u));
                         for (uint32_t k = 0; k < cnt; k++) D.items[pos + k * lanes] = (uint16_t)((uint32_t)lane | ((link + k) << 6));
                     }
-                    n_items += need;
+                    n_items += cnt * lanes;
                 } else {
                     for (uint32_t k = link; k < link + cnt; k++) {
                         const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
@@ -344,28 +389,11 @@ __device__ __forceinline__ Hit traverse_uniform_dealt(const RenderParams &P, con
             }
         }
     }
-    if (n_items == 0) return h;                          // wave-uniform
-    wave_lds_fence();
-    for (uint32_t j0 = 0; j0 < n_items; j0 += kWave) {
-        const uint32_t j = j0 + (uint32_t)lane;
-        if (j < n_items) {
-            const uint32_t it = D.items[j];
-            const uint32_t r = it & 63u, k = it >> 6;
-            const float4 ra = D.ray_a[r];
-            const float2 rb = D.ray_b[r];
-            const float4 ta = D.tris[3 * k], tb = D.tris[3 * k + 1];
-            const float2 tc = reinterpret_cast<const float2 *>(D.tris + 3 * k + 2)[0];
-            float t, u, v;
-            const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x),
-                                    mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), t, u, v);
-            if (ok & (t < tmax0) & (t > tmin))           // triangle.h:98 with the segment's initial interval
-                atomicMin(&D.keys[r], ((unsigned long long)__float_as_uint(t) << 32) | ((unsigned long long)__float_as_uint(tc.y) << 16) | k);
-        }
-    }
-    wave_lds_fence();
+    if (!any_items) return h;                            // wave-uniform
+    deal_rounds(D, lane, n_items, tmin, tmax0);
     const unsigned long long key = D.keys[lane];
-    const unsigned long long mine = h.slot >= 0 ? (((unsigned long long)__float_as_uint(h.t) << 32) | ((unsigned long long)best_rank << 16) | (uint32_t)h.slot)
-                                                : ~0ull;
+    const unsigned long long mine = (kInPlace && h.slot >= 0) ? (((unsigned long long)__float_as_uint(h.t) << 32) | ((unsigned long long)best_rank << 16) | (uint32_t)h.slot)
+                                                              : ~0ull;
     if (key < mine) {                                    // a dealt triangle is closer (or as close and visited earlier)
         h.t = __uint_as_float((uint32_t)(key >> 32));
         h.slot = (int)(key & 0xffffu);

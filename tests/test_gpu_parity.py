@@ -125,11 +125,11 @@ def test_closest_hit_matches_oracle_on_random_rays(pt, box_scene, duck_scene, bo
     tr.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("W,H,spp,depth", [(64, 64, 4, 4), (200, 120, 8, 8), (50, 34, 3, 1)])
 def test_cornell_box_image_bit_exact(pt, box_scene, box_oracle, gpu_device, W, H, spp, depth, mode):
-    """Every traversal schedule (1 = per-lane two-phase walk, 2 / 3 = wave-uniform walks) must give
-    the oracle's bytes AND the oracle's exact test counts."""
+    """Every traversal schedule (1 = per-lane two-phase walk, 2 / 3 = wave-uniform walks, 4 = mask walk with
+    dealt sparse leaves) must give the oracle's bytes AND the oracle's exact test counts."""
     ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
     _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, W, H, spp, depth, mode=mode), ref)
 
@@ -247,7 +247,7 @@ def _textured_scene(pt):
     return np.array(tris, pt.capi.TRIANGLE_DTYPE), mats, [tex0, tex1]
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 def test_textures_emissive_texture_and_inheritance_quirk(pt, ob, gpu_device, mode):
     tris, mats, texs = _textured_scene(pt)
     scene = pt.HostScene.from_arrays(tris, mats, texs)
@@ -271,7 +271,7 @@ def test_depth_zero_counts_camera_rays_and_renders_black(pt, box_scene, box_orac
     black (camera.h:49-83 returns (0,0,0)).  Found by tools/fuzz_parity.py: the kernels used to report 0 paths."""
     ref = box_oracle.render(BOX_CAMERA, 24, 16, 3, 0)
     assert ref[2]["paths"] == 24 * 16 * 3 and ref[2]["segments"] == 0 and not ref[0].any()
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 4):
         _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, 24, 16, 3, 0, mode=mode), ref)
 
 
@@ -318,7 +318,7 @@ def test_random_scenes_bit_exact_in_every_walk(pt, ob, gpu_device, seed):
     W, H, spp, depth = 40, 24, 3, 6
     ref = osc.render(cam, W, H, spp, depth, threads=8)
     info = pt.host_bvh_build(tris)[0]
-    modes = [1, 3] + ([2] if info["nodes"] - info["leaves"] <= 64 else [])
+    modes = [1, 3] + ([2, 4] if info["nodes"] - info["leaves"] <= 64 else [])
     for mode in modes:
         _assert_same(_render_gpu(pt, scene, cam, W, H, spp, depth, mode=mode, coop=0), ref)
     _assert_same(_render_gpu(pt, scene, cam, W, H, spp, depth, mode=3, coop=1), ref)      # cooperative tiles, small leaves too
@@ -454,3 +454,26 @@ def test_per_lane_test_counters_fold_before_they_can_wrap(pt, ob, duck_scene, du
         tr.close()
     assert got[0] == got[1] and got[0]["box_tests"] > (W * H) << 11
     assert np.array_equal(fb.rgb_host(), fb2.rgb_host())
+
+
+@pytest.mark.parametrize("deal_min,deal_cap", [(65, 768), (65, 64), (20, 768), (0, 768)])
+def test_dealt_walk_is_exact_whatever_is_dealt(pt, ob, box_scene, box_oracle, gpu_device, monkeypatch, deal_min, deal_cap):
+    """The dealt walk (mode 4) moves the triangle tests of leaves hit by fewer than PTAMD_DEAL_MIN lanes onto the
+    wave's item list and merges their closest hits by (t, visit rank); leaves above the threshold, and leaves whose
+    items do not fit the list (PTAMD_DEAL_CAP), are tested in place.  Every split must give the oracle's bytes and
+    counters: everything dealt (65), everything dealt into a list that overflows at once (cap 64), a low threshold,
+    nothing dealt (0 = the plain mask walk's tests run through this kernel) -- on the box, on a textured scene
+    (winner's barycentrics recomputed) and on a random soup with exact ties."""
+    monkeypatch.setenv("PTAMD_DEAL_MIN", str(deal_min))
+    monkeypatch.setenv("PTAMD_DEAL_CAP", str(deal_cap))
+    W, H, spp, depth = 104, 56, 6, 8                         # ragged right edge: lanes without a pixel help in the rounds
+    ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, W, H, spp, depth, mode=4), ref)
+    tris, mats, texs = _textured_scene(pt)
+    cam = ((0.5, 2.0, 7.0), (0.0, 0.0, -1.0), 60.0, 60.0)
+    ref = ob.OracleScene(tris, mats, texs).render(cam, 72, 48, 6, 5, threads=8)
+    _assert_same(_render_gpu(pt, pt.HostScene.from_arrays(tris, mats, texs), cam, 72, 48, 6, 5, mode=4), ref)
+    for seed in (9, 10):                                      # small random soups, coplanar geometry -> equal-t ties
+        tris, mats, texs, cam = _random_scene(pt, seed)
+        ref = ob.OracleScene(tris, mats, texs).render(cam, 40, 24, 3, 6, threads=8)
+        _assert_same(_render_gpu(pt, pt.HostScene.from_arrays(tris, mats, texs), cam, 40, 24, 3, 6, mode=4), ref)
