@@ -196,6 +196,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--band-rows", type=int, default=8)
+    ap.add_argument("--algo", default=None, choices=["fsfl", "dsfl"],
+                    help="N > 1: how row bands are dealt to ranks -- fsfl: band b to rank b %% N (fixed split); dsfl: re-dealt "
+                         "every frame from the previous frame's per-band costs, longest first (default for c5, whose "
+                         "BASELINE config names a dynamic load-balancer; fsfl otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-visible", action="store_true", help="skip the extra frames timed with the D2H copy of the frame")
     ap.add_argument("--tile-schedule", type=int, default=1, choices=[0, 1],
@@ -248,8 +252,10 @@ def main():
         spp = args.spp
         desc += " [diagnostic spp %d]" % spp
     scene, camera = load_scene(pt, kind)
+    algo = args.algo or ("dsfl" if args.config == "c5" else "fsfl")
     cfg = pt.RendererConfig(samplesPerPixel=spp, recursionDepth=depth, gpuNumber=world,
-                            resolution=pt.Resolution(W, H), showTasks=False)
+                            resolution=pt.Resolution(W, H), showTasks=False,
+                            algorithmType=pt.DSFL if algo == "dsfl" else pt.FSFL)
     cam = pt.CameraConfig(camera[0], camera[1])
     bvh = args.bvh or ("sah" if args.config == "c4" else "reference")
     desc += " [bvh=%s]" % bvh
@@ -347,8 +353,8 @@ def main():
             "config": {"workload": desc, "scene": kind, "width": W, "height": H, "spp": spp, "bounces": depth,
                        "parity": PARITY_NOTE,
                        "tile_schedule": "cost order from the previous frame" if args.tile_schedule else "raster order",
-                       "parallelism": "row-bands x%d (band_rows=%d), scene replicated, gather to rank 0"
-                                      % (world, args.band_rows)},
+                       "parallelism": "row-bands x%d (band_rows=%d, dealer=%s), scene replicated, true-size sends to rank 0"
+                                      % (world, args.band_rows, algo if world > 1 else "n/a")},
             "segments_per_frame": total["segments"] // args.steps,
             "scene_upload_s": upload_s,
             "segments_per_path": total["segments"] / max(total["paths"], 1),

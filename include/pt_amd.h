@@ -162,6 +162,18 @@ PT_API pt_status pt_render_task_async(pt_device *dev, const pt_task *task,
 PT_API pt_status pt_render_bands_async(pt_device *dev, int band_rows, int n_ranks, int rank,
                                        const pt_camera *camera, unsigned samples_per_pixel,
                                        unsigned recursion_depth, pt_stream stream);
+/* The same with an explicit band list, for dealers that do not deal b % n_ranks (the cost-fed longest-processing-time
+ * dealer of the multi-rank RenderManager, the analogue of the reference's frame-to-frame DSFL feedback,
+ * RenderManager.h:334-408): ONE launch renders the listed bands (indices into the frame's bands of band_rows rows,
+ * 0 = top; each at most once; the frame's partial last band, if listed, last).  `bands` is read before the call returns. */
+PT_API pt_status pt_render_band_list_async(pt_device *dev, int band_rows, const int *bands, int n_bands,
+                                           const pt_camera *camera, unsigned samples_per_pixel,
+                                           unsigned recursion_depth, pt_stream stream);
+/* What the bands of this device's latest row-band launch (either form) cost, in launch order: the sum over each band's
+ * 8x8 tiles of the trip counts the render kernel recorded for the cost-ordered tile schedule -- deterministic, the same
+ * whichever GPU renders the band.  Waits for that launch.  *n_bands = 0 when nothing was recorded (tile schedule off or
+ * a launch of fewer than 256 tiles).                                                                        */
+PT_API pt_status pt_band_costs_read(pt_device *dev, uint64_t *costs, int max_bands, int *n_bands);
 /* synchronizeStream(cudaStream_t), DevicePathTracer.h:222-226. */
 PT_API pt_status pt_stream_sync(pt_device *dev, pt_stream stream);
 /* waitForRenderTask(), DevicePathTracer.h:216-220. */

@@ -8,13 +8,16 @@ from . import _capi as capi
 from .host import (CameraConfig, DevicePathTracer, Framebuffer, HostScene, RendererConfig, RenderTask,
                    Resolution, SceneLoader, FSFL, DSFL, DSDL, host_bvh_build, host_sah_build, make_terrain_scene,
                    write_ppm)
-from .scheduling import (RenderManager, TaskGenerator, band_row_ranges, gather_frame, get_task_layout,
-                         pack_bands, pack_bands_strided, packed_size, row_band_tasks, unpack_bands,
-                         unpack_bands_strided)
+from .scheduling import (BandGather, RenderManager, TaskGenerator, band_row_ranges, bands_to_ranges, gather_frame,
+                         get_task_layout, lpt_assignment, pack_bands, pack_bands_strided, pack_rank_bands, packed_size,
+                         row_band_tasks, static_assignment, uniform_bands, unpack_bands, unpack_bands_strided,
+                         unpack_rank_bands)
 
 __all__ = [
     "capi", "CameraConfig", "DevicePathTracer", "Framebuffer", "HostScene", "RendererConfig", "RenderTask",
     "Resolution", "SceneLoader", "FSFL", "DSFL", "DSDL", "host_bvh_build", "host_sah_build", "make_terrain_scene", "write_ppm",
     "RenderManager", "TaskGenerator", "band_row_ranges", "gather_frame", "get_task_layout", "pack_bands",
     "packed_size", "row_band_tasks", "unpack_bands", "pack_bands_strided", "unpack_bands_strided",
+    "BandGather", "bands_to_ranges", "lpt_assignment", "pack_rank_bands", "static_assignment", "uniform_bands",
+    "unpack_rank_bands",
 ]

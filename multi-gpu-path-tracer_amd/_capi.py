@@ -80,6 +80,8 @@ _PROTOS = {
     "pt_set_bvh_mode": (C.c_int, [_vp, C.c_int]),
     "pt_render_task_async": (C.c_int, [_vp, C.POINTER(Task), C.POINTER(Camera), C.c_uint, C.c_uint, _vp]),
     "pt_render_bands_async": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(Camera), C.c_uint, C.c_uint, _vp]),
+    "pt_render_band_list_async": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(Camera), C.c_uint, C.c_uint, _vp]),
+    "pt_band_costs_read": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]),
     "pt_stream_sync": (C.c_int, [_vp, _vp]),
     "pt_device_sync": (C.c_int, [_vp]),
     "pt_stream_create": (C.c_int, [_vp, C.POINTER(_vp)]),

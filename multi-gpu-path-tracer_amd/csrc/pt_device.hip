@@ -352,6 +352,18 @@ __global__ void kat_arith_kernel(int op, const float *a, const float *b, float *
     if (o1) o1[i] = r1;
 }
 
+// Per tile row of a launch: the sum of its tiles' recorded costs (pt_band_costs_read).
+__global__ void tile_row_cost_kernel(const uint32_t *cost, int tiles_x, unsigned long long *out)
+{
+    unsigned long long sum = 0;
+    for (int i = threadIdx.x; i < tiles_x; i += blockDim.x) sum += cost[(size_t)blockIdx.x * tiles_x + i];
+    sum = wave_sum64(sum);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
 __global__ void iota_kernel(uint32_t *a, uint32_t *b, unsigned n)
 {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -532,6 +544,10 @@ struct pt_device {
     double ms_total = 0.0;
     uint64_t launches = 0;
     const char *last_kernel = "";  // what the latest render launch ran (pt_kernel_name_read)
+    // latest row-band launch, for pt_band_costs_read: its schedule (null = no costs recorded) and geometry
+    TileSchedule *band_sched = nullptr;
+    int band_tiles_x = 0, band_tiles_y = 0, band_rows_last = 0, band_local_rows = 0;
+    hipStream_t band_stream = nullptr;
 };
 
 // Traversal schedule for the uploaded tree.  The wave-uniform walks cost the UNION of the 64
@@ -1004,7 +1020,7 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.spec_pct = dev->spec_pct;
     P.fold_bits = dev->fold_bits;
     P.deal_cap = 0; P.deal_min = dev->deal_min; P.any_tex = dev->any_tex ? 1 : 0; P.lrpt = dev->lrpt;
-    P.tile_order = nullptr; P.tile_cost = nullptr;
+    P.tile_order = nullptr; P.tile_cost = nullptr; P.band_list = nullptr;
     P.legacy_mats = dev->d_legacy; P.spheres = dev->d_spheres; P.n_spheres = dev->n_spheres;
     if (dev->sah) P.stack_entries = (int)dev->sah_stack;
     P.queue_dwords = (dev->packed_queue && !dev->legacy_on) ? 1 : 2;      // the extension kernel uses the unpacked queue
@@ -1187,6 +1203,10 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         std::lock_guard<std::mutex> lk(dev->mu);
         if (sched) sched->busy--;                // last_use is recorded: from here on hipEventQuery(last_use) tells when it is idle
         dev->last_kernel = choice.name;
+        if (P.band_rows > 0) {
+            dev->band_sched = sched; dev->band_tiles_x = P.tiles_x; dev->band_tiles_y = P.tiles_y;
+            dev->band_rows_last = P.band_rows; dev->band_local_rows = P.task_h; dev->band_stream = hs;
+        }
         dev->pending.push_back(ev);
         // keep the event pool bounded when nobody reads the timings: fold finished launches in
         if (dev->pending.size() > 64) {
@@ -1255,6 +1275,93 @@ try {
     P.band_rows = band_rows; P.band_ranks = n_ranks; P.band_rank = rank;
     P.spp = (int)spp; P.depth = depth;
     return launch_render(dev, P, stream);
+} PT_CATCH_ALL
+
+pt_status pt_render_band_list_async(pt_device *dev, int band_rows, const int *bands, int n_bands, const pt_camera *camera,
+                                    unsigned spp, unsigned depth, pt_stream stream)
+try {
+    clear_error();
+    if (!dev || !camera || (n_bands > 0 && !bands)) return set_error(PT_ERR_INVALID, "null argument");
+    if (!dev->has_scene || !dev->rgb) return set_error(PT_ERR_NO_SCENE, "render before pt_upload_scene / pt_bind_framebuffer");
+    if (band_rows <= 0 || (band_rows & 1) || n_bands < 0 || spp > (1u << 24))
+        return set_error(PT_ERR_INVALID, "bad row-band request (band_rows must be a positive even number)");
+    if (n_bands == 0) return PT_OK;
+    // host-side shape check before launching a hand-written kernel: bands inside the frame, no band twice, and a
+    // partial last band of the frame only as the LAST entry (rows stay contiguous in the launch's local row index)
+    const int frame_bands = (dev->H + band_rows - 1) / band_rows;
+    std::vector<char> seen((size_t)frame_bands, 0);
+    int local_rows = 0;
+    uint32_t hash = 2166136261u;
+    for (int i = 0; i < n_bands; i++) {
+        const int b = bands[i];
+        if (b < 0 || b >= frame_bands || seen[(size_t)b]) return set_error(PT_ERR_INVALID, "band list: index out of range or repeated");
+        seen[(size_t)b] = 1;
+        const int rows = std::min(band_rows, dev->H - b * band_rows);
+        if (rows < band_rows && i != n_bands - 1) return set_error(PT_ERR_INVALID, "band list: the frame's partial last band must be the last entry");
+        local_rows += rows;
+        hash = (hash ^ (uint32_t)b) * 16777619u;
+    }
+    PT_HIP(hipSetDevice(dev->index));
+    hipStream_t hs = (hipStream_t)stream;
+    int *d_list = nullptr;
+    PT_HIP(hipMallocAsync((void **)&d_list, sizeof(int) * (size_t)n_bands, hs));
+    hipError_t e = hipMemcpyAsync(d_list, bands, sizeof(int) * (size_t)n_bands, hipMemcpyHostToDevice, hs);
+    if (e == hipSuccess) e = hipStreamSynchronize(hs) == hipSuccess ? hipSuccess : hipErrorUnknown;    // `bands` is the caller's: done with it on return
+    if (e != hipSuccess) { (void)hipFreeAsync(d_list, hs); return set_error(PT_ERR_HIP, "copying the band list to the device failed"); }
+    RenderParams P;
+    fill_params(dev, P);
+    P.cam = camera_basis(*camera);
+    P.task_w = dev->W; P.task_h = local_rows; P.task_ox = 0; P.task_oy = 0;
+    P.tiles_x = (dev->W + 7) / 8; P.tiles_y = (local_rows + 7) / 8;
+    // band_ranks / band_rank only identify the tile schedule of this band set here (the kernel reads band_list)
+    P.band_rows = band_rows; P.band_ranks = -n_bands; P.band_rank = (int)hash;
+    P.band_list = d_list;
+    P.spp = (int)spp; P.depth = depth;
+    const pt_status st = launch_render(dev, P, stream);
+    (void)hipFreeAsync(d_list, hs);                       // stream-ordered: after the launch that reads it
+    return st;
+} PT_CATCH_ALL
+
+pt_status pt_band_costs_read(pt_device *dev, uint64_t *costs, int max_bands, int *n_bands)
+try {
+    clear_error();
+    if (!dev || !costs || !n_bands || max_bands < 0) return set_error(PT_ERR_INVALID, "null argument");
+    *n_bands = 0;
+    PT_HIP(hipSetDevice(dev->index));
+    TileSchedule *sched = nullptr;
+    int tiles_x, tiles_y, band_rows, local_rows;
+    hipStream_t hs;
+    {
+        std::lock_guard<std::mutex> lk(dev->mu);
+        tiles_x = dev->band_tiles_x; tiles_y = dev->band_tiles_y; band_rows = dev->band_rows_last; local_rows = dev->band_local_rows;
+        hs = dev->band_stream;
+        for (TileSchedule *t : dev->schedules) if (t == dev->band_sched) sched = t;      // still cached?
+        if (sched) sched->busy++;
+    }
+    if (!sched || tiles_y <= 0) return PT_OK;              // nothing recorded (tile schedule off, tiny launch, or evicted)
+    struct Unpin { pt_device *d; TileSchedule *t; ~Unpin() { std::lock_guard<std::mutex> lk(d->mu); t->busy--; } } unpin{dev, sched};
+    const int nb = (local_rows + band_rows - 1) / band_rows;
+    if (nb > max_bands) return set_error(PT_ERR_INVALID, "pt_band_costs_read: output array too small");
+    DevBufs bufs;
+    unsigned long long *d_rows = nullptr;
+    PT_HIP(bufs.alloc((void **)&d_rows, sizeof(unsigned long long) * (size_t)tiles_y));
+    hipLaunchKernelGGL(dev::tile_row_cost_kernel, dim3((unsigned)tiles_y), dim3(256), 0, hs, sched->cost, tiles_x, d_rows);
+    PT_HIP(hipGetLastError());
+    std::vector<unsigned long long> rows((size_t)tiles_y);
+    PT_HIP(hipMemcpyAsync(rows.data(), d_rows, sizeof(unsigned long long) * (size_t)tiles_y, hipMemcpyDeviceToHost, hs));
+    PT_HIP(hipStreamSynchronize(hs));
+    // tile row i covers local rows [8i, 8i + 8): its cost goes to the bands those rows belong to, by row count
+    for (int k = 0; k < nb; k++) costs[k] = 0;
+    for (int i = 0; i < tiles_y; i++) {
+        const int r0 = 8 * i, r1 = std::min(8 * i + 8, local_rows);
+        for (int r = r0; r < r1;) {
+            const int k = r / band_rows, stop = std::min(r1, (k + 1) * band_rows);
+            costs[k] += rows[(size_t)i] * (unsigned long long)(stop - r) / (unsigned long long)(r1 - r0);
+            r = stop;
+        }
+    }
+    *n_bands = nb;
+    return PT_OK;
 } PT_CATCH_ALL
 
 pt_status pt_stream_sync(pt_device *dev, pt_stream stream)

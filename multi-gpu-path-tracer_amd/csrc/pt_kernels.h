@@ -35,6 +35,7 @@ struct RenderParams {
     int task_w, task_h, task_ox, task_oy;
     int tiles_x, tiles_y;             // 8x8 pixel tiles covering the task
     int band_rows, band_ranks, band_rank;   // band_ranks > 0: task rows are the rows of the row bands owned by band_rank
+    const int *band_list;             // non-null: task rows are the rows of these bands, in this order (pt_render_band_list_async)
     int spp;
     unsigned depth;
     int stack_entries;                // per-lane LDS stack slots (max_stack - 1)

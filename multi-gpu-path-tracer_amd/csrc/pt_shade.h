@@ -510,7 +510,8 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 
 // Pixel of this lane: 8x8 tile per wave; in row-band mode (pt_render_bands_async) local row j is row
 // (j % band_rows) of this rank's (j / band_rows)-th band, band b of the frame (fb rows, 0 = top)
-// belonging to rank b % band_ranks.
+// belonging to rank b % band_ranks; with an explicit band list (pt_render_band_list_async) it is row (j % band_rows)
+// of band band_list[j / band_rows].
 __device__ __forceinline__ bool tile_pixel(const RenderParams &P, int tile, int lane, int &x, int &y, int &pixel_index);
 
 __device__ __forceinline__ bool lane_pixel(const RenderParams &P, int tid, int &x, int &y, int &pixel_index)
@@ -524,7 +525,10 @@ __device__ __forceinline__ bool tile_pixel(const RenderParams &P, int tile, int 
     const int i = tile_x * 8 + (lane & 7), j = tile_y * 8 + (lane >> 3);
     const bool in_task = (tile_y < P.tiles_y) && (i < P.task_w) && (j < P.task_h);
     x = P.task_ox + i; y = P.task_oy + j;
-    if (P.band_ranks > 0) {
+    if (P.band_list) {
+        const int k = in_task ? j / P.band_rows : 0;
+        y = P.H - 1 - (P.band_list[k] * P.band_rows + (j % P.band_rows));
+    } else if (P.band_ranks > 0) {
         const int fb_row = ((j / P.band_rows) * P.band_ranks + P.band_rank) * P.band_rows + (j % P.band_rows);
         y = P.H - 1 - fb_row;
     }

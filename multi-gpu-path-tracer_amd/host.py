@@ -271,6 +271,21 @@ class DevicePathTracer:
         capi.check(capi.lib().pt_render_bands_async(self._h, band_rows, n_ranks, rank, C.byref(cam),
                                                     self.samplesPerPixel_, self.recursionDepth_, _stream_ptr(stream)))
 
+    def renderBandListAsync(self, band_rows: int, bands, stream=None):
+        """The listed row bands (indices into the frame's bands, 0 = top) in one launch: what a dealer other than
+        b % n_ranks hands this rank."""
+        cam = self.cameraConfig_.as_c()
+        arr = (C.c_int * max(len(bands), 1))(*[int(b) for b in bands])
+        capi.check(capi.lib().pt_render_band_list_async(self._h, band_rows, arr, len(bands), C.byref(cam),
+                                                        self.samplesPerPixel_, self.recursionDepth_, _stream_ptr(stream)))
+
+    def bandCosts(self, max_bands: int = 8192):
+        """Costs of the bands of the latest row-band launch, in launch order ([] when none were recorded)."""
+        out = (C.c_uint64 * max_bands)()
+        n = C.c_int()
+        capi.check(capi.lib().pt_band_costs_read(self._h, out, max_bands, C.byref(n)))
+        return [int(out[i]) for i in range(n.value)]
+
     def waitForRenderTask(self):
         capi.check(capi.lib().pt_device_sync(self._h))
 

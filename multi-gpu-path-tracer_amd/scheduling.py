@@ -122,6 +122,41 @@ def xp_cat(parts, xp):
     return xp.cat(parts) if parts else xp.zeros(0, dtype=xp.uint8)
 
 
+def static_assignment(n_bands: int, world: int) -> List[List[int]]:
+    """Band b belongs to rank b % world (FSFL: fixed split)."""
+    return [list(range(r, n_bands, world)) for r in range(world)]
+
+
+def lpt_assignment(costs, world: int) -> List[List[int]]:
+    """Cost-fed dealing for the multi-rank path (BASELINE configs[4]'s "dynamic tile load-balancer"; the analogue of
+    the reference's frame-to-frame DSFL feedback, RenderManager.h:334-408, which moves task borders toward the
+    equal-time point): bands in order of decreasing cost of the PREVIOUS frame, each to the rank with the least load so
+    far (longest processing time first).  Deterministic -- ties go to the lower band / lower rank -- so every rank
+    computes the same assignment from the same all-reduced costs, and image-neutral (per-pixel seeds).  Each rank's
+    list comes back ascending, which also puts a partial last band of the frame last, as the kernel requires."""
+    order = sorted(range(len(costs)), key=lambda b: (-int(costs[b]), b))
+    load = [0] * world
+    out = [[] for _ in range(world)]
+    for b in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(b)
+        load[r] += int(costs[b])
+    return [sorted(l) for l in out]
+
+
+def bands_to_ranges(height: int, band_rows: int, bands):
+    """Framebuffer row ranges [start, end) (row 0 = top) of the listed bands, in list order."""
+    return [(b * band_rows, min(height, (b + 1) * band_rows)) for b in bands]
+
+
+def uniform_bands(width: int, height: int, band_rows: int) -> bool:
+    """ONE predicate for both ends of the exchange (pack on every rank, unpack on rank 0): every band of the frame has
+    the same number of bytes in each of the four planes, so a plane is a [n_bands, bytes] matrix and a rank's bands are
+    a row selection of it.  Otherwise (a partial last band; odd sizes never get here, pt_bind_framebuffer refuses them)
+    both ends take the generic per-band slices."""
+    return height % band_rows == 0 and band_rows % 2 == 0 and width % 2 == 0 and height % 2 == 0
+
+
 def _plane_views(rgb_flat, yuv_flat, width: int, height: int, band_rows: int):
     """The four planes as [n_bands, bytes-per-band] views (needs height % band_rows == 0)."""
     nb = height // band_rows
@@ -148,45 +183,109 @@ def unpack_bands_strided(packed, rgb_flat, yuv_flat, width: int, height: int, ba
     return pos
 
 
-def gather_frame(packed, width: int, height: int, band_rows: int, rgb_flat, yuv_flat, group=None):
-    """The path's one exchange step: every rank contributes its packed bands, rank 0
-    scatters them into the full frame.  Uses torch.distributed.gather (RCCL on GPUs)."""
+def pack_bands_indexed(rgb_flat, yuv_flat, width: int, height: int, band_rows: int, bands):
+    """pack_bands for torch tensors and an arbitrary band list when uniform_bands(): four row selections."""
     import torch
+    idx = torch.as_tensor(list(bands), dtype=torch.long, device=rgb_flat.device)
+    return torch.cat([p.index_select(0, idx).reshape(-1) for p in _plane_views(rgb_flat, yuv_flat, width, height, band_rows)])
+
+
+def unpack_bands_indexed(packed, rgb_flat, yuv_flat, width: int, height: int, band_rows: int, bands):
+    import torch
+    idx = torch.as_tensor(list(bands), dtype=torch.long, device=rgb_flat.device)
+    pos = 0
+    for p in _plane_views(rgb_flat, yuv_flat, width, height, band_rows):
+        n = len(bands) * p.shape[1]
+        p.index_copy_(0, idx, packed[pos:pos + n].view(len(bands), p.shape[1]))
+        pos += n
+    return pos
+
+
+def pack_rank_bands(rgb_flat, yuv_flat, width: int, height: int, band_rows: int, bands, xp):
+    """A rank's bands in exchange layout (plane-major: RGB rows of all its bands, then Y, U, V rows)."""
+    if xp is not np and uniform_bands(width, height, band_rows):
+        return pack_bands_indexed(rgb_flat, yuv_flat, width, height, band_rows, bands)
+    return pack_bands(rgb_flat, yuv_flat, width, height, bands_to_ranges(height, band_rows, bands), xp)
+
+
+def unpack_rank_bands(packed, rgb_flat, yuv_flat, width: int, height: int, band_rows: int, bands):
+    if not isinstance(rgb_flat, np.ndarray) and uniform_bands(width, height, band_rows):
+        return unpack_bands_indexed(packed, rgb_flat, yuv_flat, width, height, band_rows, bands)
+    return unpack_bands(packed, rgb_flat, yuv_flat, width, height, bands_to_ranges(height, band_rows, bands))
+
+
+class BandGather:
+    """The path's one exchange step for an arbitrary band assignment: every rank's bands travel to rank 0 at their
+    TRUE size (point-to-point, one grouped batch of receives on rank 0 -- ncclGroupStart / ncclRecv x (N-1) /
+    ncclGroupEnd on RCCL; no padding to the largest share, nothing reduced, each peer on its own xGMI link to the
+    root).  Rank 0 posts its receives BEFORE it renders its own bands (post()), so the peers' bytes land while it is
+    still rendering, and scatters them into the frame afterwards (finish()).  Other ranks just send (finish())."""
+
+    def __init__(self, width: int, height: int, band_rows: int, assignment, like, group=None):
+        import torch
+        import torch.distributed as dist
+        self.width, self.height, self.band_rows, self.assignment, self.group = width, height, band_rows, assignment, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.sizes = [packed_size(width, height, bands_to_ranges(height, band_rows, bands)) for bands in assignment]
+        # RCCL ("nccl") moves device buffers directly over xGMI; with the CPU-only "gloo" backend (tests, rehearsals
+        # on one GPU) the same bytes are staged through host memory
+        self.xdev = like.device if (self.world > 1 and dist.get_backend(group) == "nccl") else torch.device("cpu")
+        self.recv = None
+        self.reqs = []
+
+    def post(self):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1 or self.rank != 0:
+            return
+        self.recv = {r: torch.empty(self.sizes[r], dtype=torch.uint8, device=self.xdev)
+                     for r in range(1, self.world) if self.sizes[r] > 0}
+        ops = [dist.P2POp(dist.irecv, buf, r, group=self.group) for r, buf in self.recv.items()]
+        self.reqs = dist.batch_isend_irecv(ops) if ops else []
+
+    def finish(self, packed, rgb_flat, yuv_flat):
+        import torch.distributed as dist
+        if self.world == 1:
+            unpack_rank_bands(packed, rgb_flat, yuv_flat, self.width, self.height, self.band_rows, self.assignment[0])
+            return
+        if self.rank != 0:
+            if self.sizes[self.rank] > 0:
+                assert packed.numel() == self.sizes[self.rank]
+                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, packed.to(self.xdev), 0, group=self.group)]):
+                    req.wait()
+            return
+        if self.recv is None:
+            self.post()
+        for req in self.reqs:
+            req.wait()
+        for r, buf in self.recv.items():                 # rank 0's own bands are already in place
+            unpack_rank_bands(buf.to(rgb_flat.device), rgb_flat, yuv_flat, self.width, self.height, self.band_rows,
+                              self.assignment[r])
+        self.recv, self.reqs = None, []
+
+
+def gather_frame(packed, width: int, height: int, band_rows: int, rgb_flat, yuv_flat, group=None, assignment=None):
+    """The path's one exchange step: every rank contributes its packed bands (static b % world split unless an
+    `assignment` -- one band list per rank -- is given), rank 0 scatters them into the full frame (BandGather)."""
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    strided = height % band_rows == 0 and width % 2 == 0 and height % 2 == 0
-    if world == 1:
-        unpack_bands(packed, rgb_flat, yuv_flat, width, height, band_row_ranges(height, band_rows, 1, 0))
-        return
-    sizes = [packed_size(width, height, band_row_ranges(height, band_rows, world, r)) for r in range(world)]
-    cap = max(sizes)
-    # RCCL ("nccl") moves device buffers directly over xGMI; with the CPU-only "gloo" backend
-    # (tests, rehearsals on one GPU) the same bytes are staged through host memory
-    xdev = packed.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    if packed.numel() == cap and packed.device == xdev:
-        send = packed
-    else:
-        send = torch.zeros(cap, dtype=torch.uint8, device=xdev)
-        send[:packed.numel()] = packed
-    recv = [torch.empty(cap, dtype=torch.uint8, device=xdev) for _ in range(world)] if rank == 0 else None
-    dist.gather(send, recv, dst=0, group=group)
-    if rank == 0:
-        for r in range(1, world):          # rank 0's own bands are already in place
-            part = recv[r][:sizes[r]].to(rgb_flat.device)
-            if strided:
-                unpack_bands_strided(part, rgb_flat, yuv_flat, width, height, band_rows, world, r)
-            else:
-                unpack_bands(part, rgb_flat, yuv_flat, width, height, band_row_ranges(height, band_rows, world, r))
+    n_bands = (height + band_rows - 1) // band_rows
+    g = BandGather(width, height, band_rows, assignment or static_assignment(n_bands, world), rgb_flat, group)
+    g.post()
+    g.finish(packed, rgb_flat, yuv_flat)
 
 
 class RenderManager:
     """RenderManager (RenderManager.h:27-659) for the render path: owns the Framebuffer and
-    this rank's DevicePathTracer, renders this rank's tasks, gathers to rank 0.
+    this rank's DevicePathTracer, renders this rank's bands, gathers to rank 0.
 
     `renderFrame()` = RenderManager::renderFrame (:410-431) + the gather that replaces UVM.
-    The frame-to-frame adaptive policies DSFL / DSDL (:264-408) are not part of this path's
-    single-frame metric; FSFL row bands (static, partition-invariant) are what runs.
+    config.algorithmType picks the dealer of the multi-rank path: FSFL = fixed split (band b to rank b % N, the
+    reference's fixed-size tasks, TaskGenerator.h:58-80); DSFL / DSDL = the reference's frame-to-frame feedback
+    (:264-408 adapt task rectangles from last frame's task times) in this path's form: the previous frame's per-band
+    costs, summed over ranks with one small all-reduce, re-deal the bands longest-processing-time-first
+    (lpt_assignment).  Images are identical under every dealer.
     """
 
     def __init__(self, config: RendererConfig, hScene: HostScene, cameraConfig: CameraConfig,
@@ -213,11 +312,24 @@ class RenderManager:
 
     def _make_tasks(self):
         res = self.config_.resolution
-        self.renderTasks_ = row_band_tasks(res.width, res.height, self.band_rows, self.world, self.rank)
-        self.ranges_ = band_row_ranges(res.height, self.band_rows, self.world, self.rank)
+        self.n_bands_ = (res.height + self.band_rows - 1) // self.band_rows
+        self.assignment_ = static_assignment(self.n_bands_, self.world)
+        self.static_ = True                       # assignment_ is the b % N split (single strided launch)
+        self.band_costs_ = None                   # previous frame's cost per band of the frame, all ranks
+        self._refresh_tasks()
+
+    def _refresh_tasks(self):
+        res = self.config_.resolution
+        mine = self.assignment_[self.rank]
+        self.ranges_ = bands_to_ranges(res.height, self.band_rows, mine)
+        self.renderTasks_ = [RenderTask(res.width, r1 - r0, 0, res.height - r1) for (r0, r1) in self.ranges_]
         # adjacent bands of one rank (world == 1) are merged into one launch
         if self.world == 1:
             self.renderTasks_ = [RenderTask(res.width, res.height, 0, 0)]
+
+    def dynamic(self) -> bool:
+        from .host import FSFL
+        return self.world > 1 and self.config_.algorithmType != FSFL
 
     # -- setters mirror RenderManager.h:214-236
     def setSamplesPerPixel(self, samples: int):
@@ -242,27 +354,55 @@ class RenderManager:
         ONE kernel launch covering all of its row bands."""
         if self.world == 1:
             self.tracer.renderTaskAsync(self.renderTasks_[0], self.streams[0])
-        else:
+        elif self.static_:
             self.tracer.renderBandsAsync(self.band_rows, self.world, self.rank, self.streams[0])
+        else:
+            self.tracer.renderBandListAsync(self.band_rows, self.assignment_[self.rank], self.streams[0])
 
     def synchronize(self):
         for s in self.streams:
             self.tracer.synchronizeStream(s)
 
+    def _redeal(self):
+        """DSFL / DSDL in this path's form: every rank contributes the costs of the bands it rendered last frame, one
+        all-reduce (n_bands 64-bit words) gives everyone the whole vector, and the same deterministic dealer runs on
+        every rank.  Costs are per-tile trip counts of the render kernel: the same whichever GPU rendered the band."""
+        import torch.distributed as dist
+        torch = self._torch
+        mine = self.assignment_[self.rank]
+        costs = self.tracer.bandCosts()
+        xdev = self.framebuffer_.rgb.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        have = torch.zeros(self.n_bands_ + 1, dtype=torch.int64)
+        if len(costs) == len(mine):
+            have[torch.as_tensor(mine, dtype=torch.long)] = torch.as_tensor(costs, dtype=torch.int64)
+            have[self.n_bands_] = 1               # this rank had costs to report
+        have = have.to(xdev)
+        dist.all_reduce(have)
+        have = have.cpu()
+        if int(have[self.n_bands_]) != self.world:
+            return                                # some rank recorded nothing (tile schedule off / tiny launch): keep the split
+        self.band_costs_ = have[:self.n_bands_].tolist()
+        new = lpt_assignment(self.band_costs_, self.world)
+        if new != self.assignment_:
+            self.assignment_ = new
+            self.static_ = False
+            self._refresh_tasks()
+
     def renderFrame(self, gather: bool = True):
         t0 = time.perf_counter()
+        res = self.config_.resolution
+        exchange = None
+        if gather and self.world > 1:
+            exchange = BandGather(res.width, res.height, self.band_rows, self.assignment_, self.framebuffer_.rgb)
+            exchange.post()                       # rank 0: receives are in flight while it renders its own bands
         self.renderTasks()
         self.synchronize()
-        if gather and self.world > 1:
-            res = self.config_.resolution
-            if res.height % self.band_rows == 0:
-                packed = pack_bands_strided(self.framebuffer_.rgb, self.framebuffer_.yuv, res.width, res.height,
-                                            self.band_rows, self.world, self.rank)
-            else:
-                packed = pack_bands(self.framebuffer_.rgb, self.framebuffer_.yuv, res.width, res.height,
-                                    self.ranges_, self._torch)
-            gather_frame(packed, res.width, res.height, self.band_rows, self.framebuffer_.rgb,
-                         self.framebuffer_.yuv)
+        if exchange is not None:
+            packed = pack_rank_bands(self.framebuffer_.rgb, self.framebuffer_.yuv, res.width, res.height,
+                                     self.band_rows, self.assignment_[self.rank], self._torch)
+            exchange.finish(packed, self.framebuffer_.rgb, self.framebuffer_.yuv)
+        if self.dynamic():
+            self._redeal()                        # next frame's split, from this frame's costs
         self.last_frame_ms = (time.perf_counter() - t0) * 1e3
 
     def getCurrentFrame(self) -> np.ndarray:

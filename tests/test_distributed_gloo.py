@@ -24,7 +24,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, W, H, band, out_path):
+def _costs(n_bands, seed=5):
+    return [int(v) for v in np.random.default_rng(seed).integers(1, 1000, n_bands)]
+
+
+def _worker(rank, world, port, W, H, band, out_path, dynamic=False):
     sys.path.insert(0, ROOT)
     pt = importlib.import_module(PKG)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -36,12 +40,17 @@ def _worker(rank, world, port, W, H, band, out_path):
     ref_yuv = torch.from_numpy(rng.integers(0, 256, total + 2 * (total // 4), dtype=np.uint8))
     rgb = torch.zeros_like(ref_rgb)
     yuv = torch.zeros_like(ref_yuv)
-    ranges = pt.band_row_ranges(H, band, world, rank)
+    n_bands = (H + band - 1) // band
+    # dynamic: the cost-fed dealer's uneven, non-strided band lists (same on every rank: same costs)
+    assignment = pt.lpt_assignment(_costs(n_bands), world) if dynamic else pt.static_assignment(n_bands, world)
+    ranges = pt.bands_to_ranges(H, band, assignment[rank])
+    assert dynamic or ranges == pt.band_row_ranges(H, band, world, rank)
     # "render": copy only this rank's bands (pack from the reference, unpack locally)
     mine = pt.pack_bands(ref_rgb, ref_yuv, W, H, ranges, torch)
     pt.unpack_bands(mine, rgb, yuv, W, H, ranges)
-    packed = pt.pack_bands(rgb, yuv, W, H, ranges, torch)
-    pt.gather_frame(packed, W, H, band, rgb, yuv)
+    packed = pt.pack_rank_bands(rgb, yuv, W, H, band, assignment[rank], torch)
+    assert torch.equal(packed, pt.pack_bands(rgb, yuv, W, H, ranges, torch))      # row-selection form == per-band slices
+    pt.gather_frame(packed, W, H, band, rgb, yuv, assignment=assignment if dynamic else None)
     if rank == 0:
         ok = bool(torch.equal(rgb, ref_rgb) and torch.equal(yuv, ref_yuv))
         open(out_path, "w").write("ok" if ok else "mismatch")
@@ -59,6 +68,32 @@ def test_gather_frame_gloo(tmp_path, world, W, H, band):
     out = tmp_path / "result.txt"
     mp.spawn(_worker, args=(world, _free_port(), W, H, band, str(out)), nprocs=world, join=True)
     assert out.read_text() == "ok"
+
+
+@pytest.mark.parametrize("world,W,H,band", [(2, 64, 36, 8), (3, 48, 50, 4), (3, 64, 64, 8), (8, 1920, 1080, 8)])
+def test_gather_frame_gloo_with_the_cost_fed_dealer(tmp_path, world, W, H, band):
+    """The same exchange under the dynamic dealer: ranks own different NUMBERS of bands in no regular pattern, every
+    rank sends its true size (no padding), a partial last band of the frame (36 % 8, 50 % 4) is some rank's last band."""
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(world, _free_port(), W, H, band, str(out), True), nprocs=world, join=True)
+    assert out.read_text() == "ok"
+
+
+def test_lpt_dealer_properties(pt):
+    for n_bands, world, seed in [(135, 8, 1), (270, 8, 2), (17, 3, 3), (5, 8, 4), (1, 2, 5)]:
+        costs = _costs(n_bands, seed)
+        a = pt.lpt_assignment(costs, world)
+        assert a == pt.lpt_assignment(list(costs), world)                               # deterministic
+        assert sorted(b for l in a for b in l) == list(range(n_bands))                  # every band exactly once
+        assert all(l == sorted(l) for l in a)                                           # ascending: a partial last band is last
+        loads = [sum(costs[b] for b in l) for l in a]
+        assert max(loads) <= sum(costs) / world + max(costs)                            # the LPT bound
+        static = [sum(costs[b] for b in l) for l in pt.static_assignment(n_bands, world)]
+        assert max(loads) <= max(static)
+    # equal costs: the dealer reproduces a round-robin-sized split (no rank more than one band ahead)
+    a = pt.lpt_assignment([7] * 135, 8)
+    assert sorted(len(l) for l in a) == [16] + [17] * 7
+    assert pt.uniform_bands(1920, 1080, 8) and not pt.uniform_bands(64, 36, 8) and not pt.uniform_bands(48, 50, 4)
 
 
 def test_single_rank_gather_is_identity(pt):

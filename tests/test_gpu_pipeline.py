@@ -86,7 +86,7 @@ def test_single_launch_bands_equal_whole_frame(pt, box_scene, box_oracle, gpu_de
     tr.close()
 
 
-def _rank_worker(rank, world, port, W, H, spp, depth, band, out_path):
+def _rank_worker(rank, world, port, W, H, spp, depth, band, out_path, algo=0, frames=2):
     import importlib
     import sys
     import torch
@@ -98,15 +98,24 @@ def _rank_worker(rank, world, port, W, H, spp, depth, band, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)          # one GPU on this box: RCCL needs one per rank
     scene = pt.SceneLoader().load(os.path.join(ROOT, "models", "cornell_box.glb")).applyCornellConvention()
     cfg = pt.RendererConfig(samplesPerPixel=spp, recursionDepth=depth, gpuNumber=world,
-                            resolution=pt.Resolution(W, H), showTasks=False)
+                            resolution=pt.Resolution(W, H), showTasks=False, algorithmType=algo)
     mgr = pt.RenderManager(cfg, scene, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]), device_idx=0, band_rows=band)
-    mgr.renderFrame()
-    mgr.renderFrame()                                                     # a second frame: buffers are reused
+    rgbs, statics, loads = [], [], []
+    for _ in range(frames):                                               # later frames: buffers are reused
+        mgr.getFramebuffer().rgb.zero_(); mgr.getFramebuffer().yuv.zero_()
+        statics.append(mgr.static_)
+        mgr.renderFrame()
+        if rank == 0:
+            rgbs.append(mgr.getCurrentFrame().copy())
     cnt = mgr.tracer.readCounters()
     tot = torch.tensor([float(cnt["segments"])], dtype=torch.float64)
     dist.all_reduce(tot)
     if rank == 0:
-        np.savez(out_path, rgb=mgr.getCurrentFrame(), yuv=mgr.getYUVFrame(), segments=np.array([tot.item() / 2]))
+        costs = mgr.band_costs_ or []
+        loads = [sum(costs[b] for b in l) for l in mgr.assignment_] if costs else []
+        np.savez(out_path, rgb=mgr.getCurrentFrame(), yuv=mgr.getYUVFrame(), segments=np.array([tot.item() / frames]),
+                 all_rgb=np.stack(rgbs), statics=np.array(statics), loads=np.array(loads, np.float64),
+                 sizes=np.array([len(l) for l in mgr.assignment_]))
     dist.barrier()
     mgr.reset()
     dist.destroy_process_group()
@@ -127,6 +136,56 @@ def test_multi_rank_render_manager_frame_equals_oracle(box_oracle, gpu_device, t
     ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
     assert np.array_equal(got["rgb"], ref[0]) and np.array_equal(got["yuv"], ref[1])
     assert int(got["segments"][0]) == ref[2]["segments"]
+
+
+def test_multi_rank_cost_fed_dealer_on_real_kernels(box_oracle, gpu_device, tmp_path):
+    """algorithmType = DSFL on the multi-rank path: frame 1 is dealt b % N, then the bands' recorded costs re-deal them
+    longest-processing-time-first (non-strided lists through pt_render_band_list_async, true-size sends).  Every frame
+    is the oracle's frame, the ranks' segments add up, the dealt loads are within one band of each other."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "frame.npz")
+    world, W, H, band, spp, depth, frames = 3, 384, 168, 8, 2, 4, 4       # 336 tiles per rank: costs are recorded
+    mp.spawn(_rank_worker, args=(world, port, W, H, spp, depth, band, out, 1, frames), nprocs=world, join=True)
+    got = np.load(out)
+    ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    for f in range(frames):
+        assert np.array_equal(got["all_rgb"][f], ref[0]), "frame %d differs from the oracle" % f
+    assert np.array_equal(got["yuv"], ref[1])
+    assert int(got["segments"][0]) == ref[2]["segments"]
+    assert got["statics"].tolist()[0] is True and not got["statics"].tolist()[-1]       # the dealer took over
+    loads = got["loads"]
+    assert len(loads) == world and loads.max() - loads.min() <= loads.sum() / 21 * 2     # 21 bands: within ~2 mean bands
+    assert int(got["sizes"].sum()) == 21
+
+
+def test_band_list_launch_and_band_costs(pt, box_scene, box_oracle, gpu_device):
+    """pt_render_band_list_async renders exactly the listed bands (partial last band included) and refuses lists the
+    kernel's row map cannot express; pt_band_costs_read gives a band the same cost whichever launch rendered it."""
+    W, H, band, spp, depth = 2048, 68, 8, 2, 3                  # 9 bands, the last of 4 rows; 256 tiles per row band
+    ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
+    costs = {}
+    for bands in ([1, 4, 6], [0, 2, 3, 5, 7, 8]):
+        tr.renderBandListAsync(band, bands); tr.waitForRenderTask()
+        c = tr.bandCosts()
+        assert len(c) == len(bands) and all(v > 0 for v in c)
+        costs.update(dict(zip(bands, c)))
+    assert np.array_equal(fb.rgb_host(), ref[0]) and np.array_equal(fb.yuv_host(), ref[1])
+    fb.rgb.zero_(); fb.yuv.zero_()
+    tr.renderBandListAsync(band, list(range(9))); tr.waitForRenderTask()
+    assert tr.bandCosts() == [costs[b] for b in range(9)]                      # a band's cost does not depend on its launch
+    assert np.array_equal(fb.rgb_host(), ref[0])
+    tr.renderBandsAsync(band, 2, 1); tr.waitForRenderTask()                    # the strided form records costs too
+    assert tr.bandCosts() == [costs[b] for b in (1, 3, 5, 7)]
+    for bad in ([0, 0], [9], [-1], [8, 2]):                                    # repeated, out of range, partial band not last
+        with pytest.raises(pt.capi.PtError) as e:
+            tr.renderBandListAsync(band, bad)
+        assert e.value.status == 1
+    tr.renderBandListAsync(band, [])                                           # nothing to do
+    tr.close()
 
 
 def _read_ppm(path):
