@@ -232,6 +232,29 @@ PT_API pt_status pt_fb_download(pt_device *dev, const uint8_t *src_device, uint8
 PT_API pt_status pt_fb_download_task(pt_device *dev, const pt_task *task, uint8_t *rgb_host,
                                      uint8_t *yuv_host, pt_stream stream);
 
+/* ---- native gather (north_star: "final RCCL gather of tile spans over xGMI", from C++ without Python) ---------------
+ * Exchange layout of a list of task rectangles of one framebuffer: plane-major over the list -- the RGB rows of every
+ * task, then their Y rows, then the U and the V samples they own (even framebuffer rows / columns, Framebuffer.h:27-35's
+ * planes).  For full-width row bands it is the byte string of the Python path's scheduling.pack_bands.               */
+PT_API pt_status pt_fb_packed_size(int width, int height, const pt_task *tasks, int n_tasks, size_t *bytes);
+/* Pack the rectangles out of / scatter them into the device's bound framebuffer, on `stream`; packed_device is DEVICE
+ * memory of pt_fb_packed_size bytes.  Asynchronous with respect to the kernels (the task list is read before return). */
+PT_API pt_status pt_fb_pack_tasks(pt_device *dev, const pt_task *tasks, int n_tasks, uint8_t *packed_device, pt_stream stream);
+PT_API pt_status pt_fb_unpack_tasks(pt_device *dev, const pt_task *tasks, int n_tasks, const uint8_t *packed_device, pt_stream stream);
+/* One process driving N GPUs (RenderManager.h:76-112: a DevicePathTracer per GPU): the replacement for the reference's
+ * implicit gather through CUDA managed memory (Framebuffer.h:27-35).  pt_gather_create makes one RCCL communicator per
+ * device (ncclCommInitAll; librccl is loaded on demand, a single device needs none).  pt_gather_frame, called once per
+ * frame after every render stream has been synchronised: device task_device[i] (an index into `devices`) rendered
+ * tasks[i]; every device but the first packs its rectangles, ONE ncclGroupStart / ncclSend + ncclRecv per peer /
+ * ncclGroupEnd moves the strings to the first device over each peer's own xGMI link, the first device scatters them
+ * into its framebuffer and the whole frame reaches rgb_host / yuv_host with one pair of copies.  All devices must have
+ * framebuffers of the same size bound.                                                                               */
+typedef struct pt_gather pt_gather;
+PT_API pt_status pt_gather_create(pt_device *const *devices, int n_devices, pt_gather **out);
+PT_API pt_status pt_gather_destroy(pt_gather *gather);
+PT_API pt_status pt_gather_frame(pt_gather *gather, const pt_task *tasks, const int *task_device, int n_tasks,
+                                 uint8_t *rgb_host, uint8_t *yuv_host);
+
 /* Device arithmetic self-test (bit-exactness contract): evaluates on the GPU
  * op 0: sincos(x)->(out0,out1); 1: a/b; 2: sqrt(a); 3: (float)((double)a / pi);
  * 4: XORWOW uniform #b (0-based) of seed (uint32)a bits -> out0.                          */

@@ -100,6 +100,12 @@ _PROTOS = {
     "pt_fb_free": (C.c_int, [_vp, _vp, _vp]),
     "pt_fb_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "pt_fb_download_task": (C.c_int, [_vp, C.POINTER(Task), _vp, _vp, _vp]),
+    "pt_fb_packed_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(Task), C.c_int, C.POINTER(C.c_size_t)]),
+    "pt_fb_pack_tasks": (C.c_int, [_vp, C.POINTER(Task), C.c_int, _vp, _vp]),
+    "pt_fb_unpack_tasks": (C.c_int, [_vp, C.POINTER(Task), C.c_int, _vp, _vp]),
+    "pt_gather_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(_vp)]),
+    "pt_gather_destroy": (C.c_int, [_vp]),
+    "pt_gather_frame": (C.c_int, [_vp, C.POINTER(Task), C.POINTER(C.c_int), C.c_int, _vp, _vp]),
     "pt_set_tile_schedule": (C.c_int, [_vp, C.c_int]),
     "pt_set_cooperative_mode": (C.c_int, [_vp, C.c_int]),
     "pt_set_legacy_scene": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t]),

@@ -3,8 +3,10 @@
 // (RenderManager.h:27-659): deferred parameter hot-swap, FSFL / DSFL / DSDL task policies,
 // task-border overlay, and the two-barrier frame protocol (:410-431).
 //
-// Differences by design: the scene is uploaded once per GPU in bulk; every worker gathers
-// its finished rectangle into the shared host Framebuffer explicitly (no managed memory);
+// Differences by design: the scene is uploaded once per GPU in bulk; there is no managed memory -- with ONE GPU every
+// worker copies its finished rectangle into the shared host Framebuffer itself, with SEVERAL the frame is gathered
+// natively after the frame barrier (pt_gather_frame: every peer GPU packs its rectangles, one grouped RCCL
+// ncclSend / ncclRecv exchange brings them to GPU 0 over xGMI, one device-to-host copy of the whole frame);
 // every task is rendered exactly once also with streamsPerGpu > 1.  The image does not
 // depend on the task partition (per-pixel seeds), only the timing does.
 #pragma once
@@ -56,6 +58,7 @@ public:
         barrier_.wait();                                   // release the workers so they can exit
         for (auto &perGpu : streamThreads_) for (auto &t : perGpu) t->join();
         streamThreads_.clear();
+        if (gather_) { pt_gather_destroy(gather_); gather_ = nullptr; }
         devicePathTracers_.clear();
     }
 
@@ -75,10 +78,31 @@ public:
             streamThreads_.emplace_back();
             for (unsigned j = 0; j < config_.streamsPerGpu; j++) {
                 int taskIdx = (int)(i * config_.streamsPerGpu + j);
-                streamThreads_[i].push_back(std::make_shared<StreamThread>((int)i, taskIdx, devicePathTracers_[i], renderTasks_, barrier_));
+                streamThreads_[i].push_back(std::make_shared<StreamThread>((int)i, taskIdx, devicePathTracers_[i], renderTasks_, barrier_,
+                                                                          /*gatherOnWorker=*/config_.gpuNumber == 1));
                 streamThreads_[i][j]->start();
             }
         }
+        if (config_.gpuNumber > 1) {                       // one RCCL communicator per GPU, made once per setup
+            std::vector<pt_device *> devs;
+            for (auto &dpt : devicePathTracers_) devs.push_back(dpt->handle());
+            checkPtErrors(pt_gather_create(devs.data(), (int)devs.size(), &gather_));
+        }
+    }
+
+    // The frame's one exchange step with several GPUs: task k was rendered by GPU k / streamsPerGpu (setup()).
+    void gatherFrame()
+    {
+        if (!gather_) return;
+        std::vector<pt_task> tasks;
+        std::vector<int> owner;
+        for (size_t k = 0; k < renderTasks_.size(); k++) {
+            const RenderTask &t = renderTasks_[k];
+            tasks.push_back(pt_task{t.width, t.height, t.offset_x, t.offset_y});
+            owner.push_back((int)(k / config_.streamsPerGpu));
+        }
+        checkPtErrors(pt_gather_frame(gather_, tasks.data(), owner.data(), (int)tasks.size(), framebuffer_->getRGBPtr(),
+                                      framebuffer_->getYUVPtr()));
     }
 
     // ---- deferred setters (RenderManager.h:114-248): applied at the top of the next frame
@@ -237,7 +261,8 @@ public:
         if (config_.algorithmType == DSFL) adjustTasksDSFL();
         else if (config_.algorithmType == DSDL) adjustTasksDSDL();
         barrier_.wait();     // release the workers
-        barrier_.wait();     // all tasks rendered and gathered
+        barrier_.wait();     // all tasks rendered (and, with one GPU, gathered by their workers)
+        gatherFrame();       // several GPUs: one RCCL exchange to GPU 0 + one copy to the host
         if (config_.showTasks) markTasks();
     }
 
@@ -360,6 +385,7 @@ private:
     int threadCount_ = 1;
     SceneLoader &sceneLoader_;
     int bisectionDepth_ = 0;
+    pt_gather *gather_ = nullptr;
 };
 
 } // namespace ptamd

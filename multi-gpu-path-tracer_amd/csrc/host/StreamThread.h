@@ -1,6 +1,7 @@
 // StreamThread.h -- one worker per (GPU, stream), as StreamThread.h:16-115: between the two
 // frame barriers it launches its task on its stream, waits for it, records the wall time in
-// RenderTask::time and (new) copies the task's pixels into the shared host framebuffer.
+// RenderTask::time and (new, single-GPU runs) copies the task's pixels into the shared host framebuffer; with several
+// GPUs the RenderManager gathers all rectangles over RCCL after the frame barrier instead.
 // Unlike the reference (tasks_[deviceIdx], StreamThread.h:83) every worker owns task number
 // `taskIdx`, so streamsPerGpu > 1 renders every task exactly once.
 #pragma once
@@ -18,9 +19,12 @@ namespace ptamd {
 
 class StreamThread {
 public:
+    // gatherOnWorker: this worker copies its finished rectangle to the host itself (single GPU); otherwise the
+    // RenderManager gathers all devices' rectangles in one RCCL exchange after the frame barrier.
     StreamThread(int device_idx, int task_idx, std::shared_ptr<DevicePathTracer> devicePathTracer,
-                 std::vector<RenderTask> &tasks, Barrier &barrier)
-        : deviceIdx{device_idx}, taskIdx{task_idx}, devicePathTracer{devicePathTracer}, tasks_{tasks}, barrier_{barrier}
+                 std::vector<RenderTask> &tasks, Barrier &barrier, bool gatherOnWorker = true)
+        : deviceIdx{device_idx}, taskIdx{task_idx}, devicePathTracer{devicePathTracer}, tasks_{tasks}, barrier_{barrier},
+          gatherOnWorker_{gatherOnWorker}
     {
         stream = devicePathTracer->createStream();
     }
@@ -48,7 +52,7 @@ public:
                 devicePathTracer->synchronizeStream(stream);
                 auto stop = std::chrono::high_resolution_clock::now();
                 task.time = (int)std::chrono::duration_cast<std::chrono::milliseconds>(stop - start).count();
-                devicePathTracer->gatherTask(task, stream);
+                if (gatherOnWorker_) devicePathTracer->gatherTask(task, stream);
             }
             barrier_.wait();                       // frame end
             if (shouldTerminate) return;
@@ -64,6 +68,7 @@ private:
     std::thread thread_{};
     std::vector<RenderTask> &tasks_;
     Barrier &barrier_;
+    bool gatherOnWorker_ = true;
 };
 
 } // namespace ptamd

@@ -12,6 +12,8 @@
 // a divergent gather workload.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h>          // types and prototypes only: librccl is dlopen()ed by the native gather, never linked
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -350,6 +352,43 @@ __global__ void kat_arith_kernel(int op, const float *a, const float *b, float *
     }
     o0[i] = r0;
     if (o1) o1[i] = r1;
+}
+
+// ---- exchange layout of a set of task rectangles (the native gather, pt_gather_frame) ------------------------------
+// A device's rendered rectangles travel as ONE byte string, plane-major over its task list: the RGB rows of task 0,
+// task 1, ..., then their Y rows, then the U samples they own (even framebuffer rows and columns), then the V samples.
+// For full-width row bands this is byte for byte scheduling.pack_bands (the Python path's layout).
+struct PackTask {
+    int x0, x1, r0, r1;               // pixel columns [x0, x1), framebuffer rows [r0, r1) (row 0 = top)
+    int k0, k1, c0, c1;               // chroma columns [k0, k1), chroma rows [c0, c1)
+    size_t off_rgb, off_y, off_u, off_v;   // byte offsets of this task's four pieces in the packed string
+};
+
+template <bool kPack>
+__global__ void pack_tasks_kernel(uint8_t *rgb, uint8_t *yuv, int W, int H, const PackTask *tasks, uint8_t *packed)
+{
+    const PackTask t = tasks[blockIdx.y];
+    const size_t w = (size_t)(t.x1 - t.x0), h = (size_t)(t.r1 - t.r0), cw = (size_t)(t.k1 - t.k0), ch = (size_t)(t.c1 - t.c0);
+    const size_t n_rgb = w * 3 * h, n_y = w * h, n_c = cw * ch, total = (size_t)W * H;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rgb + n_y + 2 * n_c; i += stride) {
+        uint8_t *fb, *pk;
+        if (i < n_rgb) {
+            const size_t row = i / (w * 3), col = i % (w * 3);
+            fb = rgb + ((size_t)(t.r0 + row) * W + t.x0) * 3 + col; pk = packed + t.off_rgb + i;
+        } else if (i < n_rgb + n_y) {
+            const size_t j = i - n_rgb, row = j / w, col = j % w;
+            fb = yuv + (size_t)(t.r0 + row) * W + t.x0 + col; pk = packed + t.off_y + j;
+        } else {
+            size_t j = i - n_rgb - n_y;
+            const int plane = j >= n_c ? 1 : 0;
+            if (plane) j -= n_c;
+            const size_t row = j / cw, col = j % cw;
+            fb = yuv + total + (size_t)plane * (total / 4) + (size_t)(t.c0 + row) * (W / 2) + t.k0 + col;
+            pk = packed + (plane ? t.off_v : t.off_u) + j;
+        }
+        if (kPack) *pk = *fb; else *fb = *pk;
+    }
 }
 
 // Per tile row of a launch: the sum of its tiles' recorded costs (pt_band_costs_read).
@@ -1573,6 +1612,255 @@ try {
         }
     }
     PT_HIP(hipStreamSynchronize(hs));
+    return PT_OK;
+} PT_CATCH_ALL
+
+// Layout of a task list in the exchange string (host mirror of PackTask); returns the string's length.
+static size_t layout_tasks(int W, int H, const pt_task *tasks, int n, std::vector<dev::PackTask> &out)
+{
+    out.assign((size_t)n, dev::PackTask());
+    const int half = W / 2;
+    size_t n_rgb = 0, n_y = 0, n_c = 0;
+    for (int i = 0; i < n; i++) {
+        dev::PackTask &t = out[(size_t)i];
+        const pt_task &k = tasks[i];
+        t.x0 = k.offset_x; t.x1 = k.offset_x + k.width;
+        t.r0 = H - k.offset_y - k.height; t.r1 = H - k.offset_y;           // framebuffer rows, 0 = top (DevicePathTracer.h:79)
+        t.c0 = (t.r0 + 1) / 2; t.c1 = std::min((t.r1 + 1) / 2, H / 2);     // chroma rows of its even framebuffer rows
+        t.k0 = (t.x0 + 1) / 2; t.k1 = std::min((t.x1 + 1) / 2, half);      // chroma columns of its even columns
+        if (t.c1 < t.c0) t.c1 = t.c0;
+        if (t.k1 < t.k0) t.k1 = t.k0;
+        n_rgb += (size_t)(t.x1 - t.x0) * 3 * (size_t)(t.r1 - t.r0);
+        n_y += (size_t)(t.x1 - t.x0) * (size_t)(t.r1 - t.r0);
+        n_c += (size_t)(t.k1 - t.k0) * (size_t)(t.c1 - t.c0);
+    }
+    size_t o_rgb = 0, o_y = n_rgb, o_u = n_rgb + n_y, o_v = n_rgb + n_y + n_c;
+    for (dev::PackTask &t : out) {
+        t.off_rgb = o_rgb; t.off_y = o_y; t.off_u = o_u; t.off_v = o_v;
+        o_rgb += (size_t)(t.x1 - t.x0) * 3 * (size_t)(t.r1 - t.r0);
+        o_y += (size_t)(t.x1 - t.x0) * (size_t)(t.r1 - t.r0);
+        const size_t c = (size_t)(t.k1 - t.k0) * (size_t)(t.c1 - t.c0);
+        o_u += c; o_v += c;
+    }
+    return n_rgb + n_y + 2 * n_c;
+}
+
+static pt_status check_tasks(const pt_device *dev, const pt_task *tasks, int n)
+{
+    if (!dev->rgb) return set_error(PT_ERR_NO_SCENE, "no framebuffer bound");
+    for (int i = 0; i < n; i++) {
+        const pt_task &t = tasks[i];
+        if (t.width < 0 || t.height < 0 || t.offset_x < 0 || t.offset_y < 0 || t.offset_x + t.width > dev->W || t.offset_y + t.height > dev->H)
+            return set_error(PT_ERR_INVALID, "task rectangle leaves the framebuffer");
+    }
+    return PT_OK;
+}
+
+// Pack (or unpack) on `hs`; `packed` is a device buffer of at least the returned size.  No synchronisation.
+static pt_status run_pack(pt_device *dev, bool pack, const pt_task *tasks, int n, uint8_t *packed, hipStream_t hs, size_t *bytes_out)
+{
+    std::vector<dev::PackTask> lay;
+    const size_t bytes = layout_tasks(dev->W, dev->H, tasks, n, lay);
+    if (bytes_out) *bytes_out = bytes;
+    if (bytes == 0 || n == 0) return PT_OK;
+    dev::PackTask *d_lay = nullptr;
+    PT_HIP(hipMallocAsync((void **)&d_lay, sizeof(dev::PackTask) * lay.size(), hs));
+    hipError_t e = hipMemcpyAsync(d_lay, lay.data(), sizeof(dev::PackTask) * lay.size(), hipMemcpyHostToDevice, hs);
+    if (e == hipSuccess) e = hipStreamSynchronize(hs);       // `lay` is a local: the copy must have read it before we return
+    if (e != hipSuccess) { (void)hipFreeAsync(d_lay, hs); return set_error(PT_ERR_HIP, "copying the task layout to the device failed"); }
+    const dim3 grid(64, (unsigned)n);
+    if (pack) hipLaunchKernelGGL(dev::pack_tasks_kernel<true>, grid, dim3(256), 0, hs, dev->rgb, dev->yuv, dev->W, dev->H, d_lay, packed);
+    else hipLaunchKernelGGL(dev::pack_tasks_kernel<false>, grid, dim3(256), 0, hs, dev->rgb, dev->yuv, dev->W, dev->H, d_lay, packed);
+    e = hipGetLastError();
+    (void)hipFreeAsync(d_lay, hs);
+    if (e != hipSuccess) return set_error(PT_ERR_HIP, std::string("pack kernel launch failed: ") + hipGetErrorString(e));
+    return PT_OK;
+}
+
+pt_status pt_fb_packed_size(int width, int height, const pt_task *tasks, int n_tasks, size_t *bytes)
+try {
+    clear_error();
+    if (width <= 0 || height <= 0 || n_tasks < 0 || (n_tasks && !tasks) || !bytes) return set_error(PT_ERR_INVALID, "bad argument");
+    std::vector<dev::PackTask> lay;
+    *bytes = layout_tasks(width, height, tasks, n_tasks, lay);
+    return PT_OK;
+} PT_CATCH_ALL
+
+pt_status pt_fb_pack_tasks(pt_device *dev, const pt_task *tasks, int n_tasks, uint8_t *packed_device, pt_stream stream)
+try {
+    clear_error();
+    if (!dev || n_tasks < 0 || (n_tasks && (!tasks || !packed_device))) return set_error(PT_ERR_INVALID, "bad argument");
+    pt_status st = check_tasks(dev, tasks, n_tasks);
+    if (st != PT_OK) return st;
+    PT_HIP(hipSetDevice(dev->index));
+    return run_pack(dev, true, tasks, n_tasks, packed_device, (hipStream_t)stream, nullptr);
+} PT_CATCH_ALL
+
+pt_status pt_fb_unpack_tasks(pt_device *dev, const pt_task *tasks, int n_tasks, const uint8_t *packed_device, pt_stream stream)
+try {
+    clear_error();
+    if (!dev || n_tasks < 0 || (n_tasks && (!tasks || !packed_device))) return set_error(PT_ERR_INVALID, "bad argument");
+    pt_status st = check_tasks(dev, tasks, n_tasks);
+    if (st != PT_OK) return st;
+    PT_HIP(hipSetDevice(dev->index));
+    return run_pack(dev, false, tasks, n_tasks, const_cast<uint8_t *>(packed_device), (hipStream_t)stream, nullptr);
+} PT_CATCH_ALL
+
+// ---- native gather over RCCL (one process, one communicator per GPU) ------------------------------------------------
+// librccl is loaded on first use of a group of more than one device: a single-GPU build or run never needs it.
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+    bool load()
+    {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { error = std::string("cannot load librccl: ") + dlerror(); return false; }
+#define PT_SYM(field, sym) field = (decltype(field))dlsym(lib, sym); if (!field) { error = std::string("librccl lacks ") + sym; return false; }
+        PT_SYM(CommInitAll, "ncclCommInitAll") PT_SYM(CommDestroy, "ncclCommDestroy") PT_SYM(GroupStart, "ncclGroupStart")
+        PT_SYM(GroupEnd, "ncclGroupEnd") PT_SYM(Send, "ncclSend") PT_SYM(Recv, "ncclRecv") PT_SYM(GetErrorString, "ncclGetErrorString")
+#undef PT_SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+} // namespace
+
+struct pt_gather {
+    std::vector<pt_device *> devs;
+    std::vector<ncclComm_t> comms;           // one per device (rank i = devs[i]); empty for a single device
+    std::vector<hipStream_t> streams;        // one per device
+    std::vector<uint8_t *> send;             // device i's packed string (i > 0), on device i
+    std::vector<uint8_t *> recv;             // where device 0 receives device i's string
+    std::vector<size_t> cap;                 // capacity of send[i] / recv[i]
+};
+
+#define PT_NCCL(call)                                                                                       \
+    do {                                                                                                    \
+        ncclResult_t r_ = (call);                                                                           \
+        if (r_ != ncclSuccess)                                                                              \
+            return set_error(PT_ERR_HIP, std::string("RCCL ERROR = ") + std::to_string((int)r_) + " (" +    \
+                                             g_rccl.GetErrorString(r_) + ") at " + __FILE__ + ":" +         \
+                                             std::to_string(__LINE__) + " '" #call "'");                    \
+    } while (0)
+
+pt_status pt_gather_create(pt_device *const *devices, int n_devices, pt_gather **out)
+try {
+    clear_error();
+    if (!devices || n_devices <= 0 || !out) return set_error(PT_ERR_INVALID, "bad argument");
+    std::unique_ptr<pt_gather> g(new pt_gather());
+    std::vector<int> ids;
+    for (int i = 0; i < n_devices; i++) {
+        if (!devices[i]) return set_error(PT_ERR_INVALID, "null device");
+        for (int id : ids) if (id == devices[i]->index) return set_error(PT_ERR_INVALID, "pt_gather_create: the same GPU twice (one communicator rank per GPU)");
+        ids.push_back(devices[i]->index);
+        g->devs.push_back(devices[i]);
+    }
+    g->send.assign((size_t)n_devices, nullptr); g->recv.assign((size_t)n_devices, nullptr); g->cap.assign((size_t)n_devices, 0);
+    for (int i = 0; i < n_devices; i++) {
+        PT_HIP(hipSetDevice(ids[(size_t)i]));
+        hipStream_t s;
+        PT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        g->streams.push_back(s);
+    }
+    if (n_devices > 1) {
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        if (!g_rccl.load()) return set_error(PT_ERR_UNSUPPORTED, g_rccl.error);
+        g->comms.assign((size_t)n_devices, nullptr);
+        PT_NCCL(g_rccl.CommInitAll(g->comms.data(), n_devices, ids.data()));
+    }
+    *out = g.release();
+    return PT_OK;
+} PT_CATCH_ALL
+
+pt_status pt_gather_destroy(pt_gather *g)
+try {
+    clear_error();
+    if (!g) return PT_OK;
+    for (size_t i = 0; i < g->devs.size(); i++) {
+        (void)hipSetDevice(g->devs[i]->index);
+        if (i < g->streams.size() && g->streams[i]) { (void)hipStreamSynchronize(g->streams[i]); (void)hipStreamDestroy(g->streams[i]); }
+        (void)hipFree(g->send[i]);
+    }
+    if (!g->devs.empty()) { (void)hipSetDevice(g->devs[0]->index); for (uint8_t *p : g->recv) (void)hipFree(p); }
+    for (ncclComm_t c : g->comms) if (c) (void)g_rccl.CommDestroy(c);
+    delete g;
+    return PT_OK;
+} PT_CATCH_ALL
+
+pt_status pt_gather_frame(pt_gather *g, const pt_task *tasks, const int *task_device, int n_tasks, uint8_t *rgb_host, uint8_t *yuv_host)
+try {
+    clear_error();
+    if (!g || n_tasks < 0 || (n_tasks && (!tasks || !task_device)) || !rgb_host || !yuv_host) return set_error(PT_ERR_INVALID, "bad argument");
+    const int n = (int)g->devs.size();
+    pt_device *root = g->devs[0];
+    if (!root->rgb) return set_error(PT_ERR_NO_SCENE, "no framebuffer bound");
+    // every device's rectangles, in task order
+    std::vector<std::vector<pt_task>> mine((size_t)n);
+    for (int i = 0; i < n_tasks; i++) {
+        if (task_device[i] < 0 || task_device[i] >= n) return set_error(PT_ERR_INVALID, "task_device entry out of range");
+        if (tasks[i].width > 0 && tasks[i].height > 0) mine[(size_t)task_device[i]].push_back(tasks[i]);
+    }
+    std::vector<size_t> bytes((size_t)n, 0);
+    for (int i = 1; i < n; i++) {
+        pt_device *d = g->devs[(size_t)i];
+        if (d->W != root->W || d->H != root->H) return set_error(PT_ERR_INVALID, "pt_gather_frame: the devices' framebuffers differ in size");
+        pt_status st = check_tasks(d, mine[(size_t)i].data(), (int)mine[(size_t)i].size());
+        if (st != PT_OK) return st;
+        std::vector<dev::PackTask> lay;
+        bytes[(size_t)i] = layout_tasks(d->W, d->H, mine[(size_t)i].data(), (int)mine[(size_t)i].size(), lay);
+        if (bytes[(size_t)i] > g->cap[(size_t)i]) {                       // grow the two staging strings of this peer
+            PT_HIP(hipSetDevice(d->index));
+            (void)hipFree(g->send[(size_t)i]); g->send[(size_t)i] = nullptr;
+            PT_HIP(hipMalloc((void **)&g->send[(size_t)i], bytes[(size_t)i]));
+            PT_HIP(hipSetDevice(root->index));
+            (void)hipFree(g->recv[(size_t)i]); g->recv[(size_t)i] = nullptr;
+            PT_HIP(hipMalloc((void **)&g->recv[(size_t)i], bytes[(size_t)i]));
+            g->cap[(size_t)i] = bytes[(size_t)i];
+        }
+    }
+    // 1. every peer packs its rectangles on its own stream (its render streams have been synchronised by the caller)
+    for (int i = 1; i < n; i++) {
+        if (bytes[(size_t)i] == 0) continue;
+        PT_HIP(hipSetDevice(g->devs[(size_t)i]->index));
+        pt_status st = run_pack(g->devs[(size_t)i], true, mine[(size_t)i].data(), (int)mine[(size_t)i].size(), g->send[(size_t)i], g->streams[(size_t)i], nullptr);
+        if (st != PT_OK) return st;
+    }
+    // 2. ONE grouped exchange: peer i sends its string to rank 0 over its own xGMI link, rank 0 posts the matching receives
+    if (n > 1) {
+        PT_NCCL(g_rccl.GroupStart());
+        for (int i = 1; i < n; i++) {
+            if (bytes[(size_t)i] == 0) continue;
+            PT_NCCL(g_rccl.Send(g->send[(size_t)i], bytes[(size_t)i], ncclUint8, 0, g->comms[(size_t)i], g->streams[(size_t)i]));
+            PT_NCCL(g_rccl.Recv(g->recv[(size_t)i], bytes[(size_t)i], ncclUint8, i, g->comms[0], g->streams[0]));
+        }
+        PT_NCCL(g_rccl.GroupEnd());
+    }
+    // 3. rank 0 scatters what it received into its framebuffer (its own rectangles are there already) and hands the
+    //    whole frame to the host with ONE pair of copies
+    PT_HIP(hipSetDevice(root->index));
+    for (int i = 1; i < n; i++) {
+        if (bytes[(size_t)i] == 0) continue;
+        pt_status st = run_pack(root, false, mine[(size_t)i].data(), (int)mine[(size_t)i].size(), g->recv[(size_t)i], g->streams[0], nullptr);
+        if (st != PT_OK) return st;
+    }
+    const size_t total = (size_t)root->W * (size_t)root->H;
+    PT_HIP(hipMemcpyAsync(rgb_host, root->rgb, total * 3, hipMemcpyDeviceToHost, g->streams[0]));
+    PT_HIP(hipMemcpyAsync(yuv_host, root->yuv, total + 2 * (total / 4), hipMemcpyDeviceToHost, g->streams[0]));
+    PT_HIP(hipStreamSynchronize(g->streams[0]));
+    for (int i = 1; i < n; i++) { PT_HIP(hipSetDevice(g->devs[(size_t)i]->index)); PT_HIP(hipStreamSynchronize(g->streams[(size_t)i])); }
     return PT_OK;
 } PT_CATCH_ALL
 

@@ -316,6 +316,9 @@ class RenderManager:
         self.assignment_ = static_assignment(self.n_bands_, self.world)
         self.static_ = True                       # assignment_ is the b % N split (single strided launch)
         self.band_costs_ = None                   # previous frame's cost per band of the frame, all ranks
+        if getattr(self, "_pending_costs", None) is not None:
+            self._pending_costs[1].wait()         # a cost exchange of the old geometry: complete it, drop it
+        self._pending_costs = None
         self._refresh_tasks()
 
     def _refresh_tasks(self):
@@ -363,21 +366,28 @@ class RenderManager:
         for s in self.streams:
             self.tracer.synchronizeStream(s)
 
-    def _redeal(self):
-        """DSFL / DSDL in this path's form: every rank contributes the costs of the bands it rendered last frame, one
-        all-reduce (n_bands 64-bit words) gives everyone the whole vector, and the same deterministic dealer runs on
-        every rank.  Costs are per-tile trip counts of the render kernel: the same whichever GPU rendered the band."""
+    def _begin_redeal(self):
+        """DSFL / DSDL in this path's form, first half (right after this rank's launch has finished): the costs of the
+        bands it just rendered go into one ASYNCHRONOUS all-reduce (n_bands + 1 64-bit words) that gives every rank the
+        whole vector.  Nobody waits here -- the peers are not held up by rank 0's unpacking, and rank 0 not by them."""
         import torch.distributed as dist
         torch = self._torch
         mine = self.assignment_[self.rank]
         costs = self.tracer.bandCosts()
-        xdev = self.framebuffer_.rgb.device if dist.get_backend() == "nccl" else torch.device("cpu")
         have = torch.zeros(self.n_bands_ + 1, dtype=torch.int64)
         if len(costs) == len(mine):
             have[torch.as_tensor(mine, dtype=torch.long)] = torch.as_tensor(costs, dtype=torch.int64)
             have[self.n_bands_] = 1               # this rank had costs to report
+        xdev = self.framebuffer_.rgb.device if dist.get_backend() == "nccl" else torch.device("cpu")
         have = have.to(xdev)
-        dist.all_reduce(have)
+        self._pending_costs = (have, dist.all_reduce(have, async_op=True))
+
+    def _finish_redeal(self):
+        """Second half, at the start of the next frame: the same deterministic dealer runs on every rank over the summed
+        costs (per-tile trip counts of the render kernel: the same whichever GPU rendered the band)."""
+        have, work = self._pending_costs
+        self._pending_costs = None
+        work.wait()
         have = have.cpu()
         if int(have[self.n_bands_]) != self.world:
             return                                # some rank recorded nothing (tile schedule off / tiny launch): keep the split
@@ -391,18 +401,20 @@ class RenderManager:
     def renderFrame(self, gather: bool = True):
         t0 = time.perf_counter()
         res = self.config_.resolution
+        if self._pending_costs is not None:
+            self._finish_redeal()                 # this frame's split, from the previous frame's costs
         exchange = None
         if gather and self.world > 1:
             exchange = BandGather(res.width, res.height, self.band_rows, self.assignment_, self.framebuffer_.rgb)
             exchange.post()                       # rank 0: receives are in flight while it renders its own bands
         self.renderTasks()
         self.synchronize()
+        if self.dynamic():
+            self._begin_redeal()
         if exchange is not None:
             packed = pack_rank_bands(self.framebuffer_.rgb, self.framebuffer_.yuv, res.width, res.height,
                                      self.band_rows, self.assignment_[self.rank], self._torch)
             exchange.finish(packed, self.framebuffer_.rgb, self.framebuffer_.yuv)
-        if self.dynamic():
-            self._redeal()                        # next frame's split, from this frame's costs
         self.last_frame_ms = (time.perf_counter() - t0) * 1e3
 
     def getCurrentFrame(self) -> np.ndarray:
@@ -412,4 +424,7 @@ class RenderManager:
         return self.framebuffer_.yuv_host()
 
     def reset(self):
+        if self._pending_costs is not None:
+            self._pending_costs[1].wait()
+            self._pending_costs = None
         self.tracer.close()

@@ -303,3 +303,66 @@ def test_cost_ordered_tile_schedule_never_changes_a_byte(pt, box_scene, gpu_devi
         tr.renderTaskAsync(t); tr.renderTaskAsync(t); tr.waitForRenderTask()
     tr.setTileSchedule(0)
     tr.close()
+
+
+def _tasks_c(pt, tasks):
+    arr = (pt.capi.Task * max(len(tasks), 1))()
+    for i, t in enumerate(tasks):
+        arr[i] = pt.capi.Task(t.width, t.height, t.offset_x, t.offset_y)
+    return arr
+
+
+def test_native_pack_equals_python_pack_bands_and_round_trips(pt, box_scene, gpu_device):
+    """The native gather's device-side packing (pt_fb_pack_tasks, what every peer GPU runs before its ncclSend) against
+    the Python path's scheduling.pack_bands byte for byte on row bands, then pack -> clear -> unpack on ragged rectangles
+    (odd offsets: chroma samples belong to whoever owns the even row / column), and the single-device pt_gather."""
+    import ctypes as C
+    import torch
+    W, H, spp, depth, band = 200, 76, 2, 3, 8
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
+    tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+    rgb0, yuv0 = fb.rgb.clone(), fb.yuv.clone()
+    lib = pt.capi.lib()
+    for world, rank in [(3, 1), (2, 0), (4, 3)]:                                  # 76 % 8 = 4: a partial last band
+        tasks = pt.row_band_tasks(W, H, band, world, rank)
+        ranges = pt.band_row_ranges(H, band, world, rank)
+        n = C.c_size_t()
+        pt.capi.check(lib.pt_fb_packed_size(W, H, _tasks_c(pt, tasks), len(tasks), C.byref(n)))
+        assert n.value == pt.packed_size(W, H, ranges)
+        packed = torch.zeros(n.value, dtype=torch.uint8, device="cuda")
+        pt.capi.check(lib.pt_fb_pack_tasks(tr._h, _tasks_c(pt, tasks), len(tasks), C.c_void_p(packed.data_ptr()), None))
+        torch.cuda.synchronize()
+        assert torch.equal(packed, pt.pack_bands(fb.rgb, fb.yuv, W, H, ranges, torch))
+    ragged = [pt.RenderTask(37, 30, 0, 0), pt.RenderTask(163, 30, 37, 0), pt.RenderTask(200, 1, 0, 30),
+              pt.RenderTask(101, 45, 0, 31), pt.RenderTask(99, 45, 101, 31)]       # a partition of the frame
+    sizes = []
+    for group in (ragged[:2], ragged[2:]):
+        n = C.c_size_t()
+        pt.capi.check(lib.pt_fb_packed_size(W, H, _tasks_c(pt, group), len(group), C.byref(n)))
+        sizes.append(n.value)
+        packed = torch.zeros(n.value, dtype=torch.uint8, device="cuda")
+        pt.capi.check(lib.pt_fb_pack_tasks(tr._h, _tasks_c(pt, group), len(group), C.c_void_p(packed.data_ptr()), None))
+        torch.cuda.synchronize()
+        if group is ragged[:2]:
+            keep = packed
+            keep_group = group
+    assert sum(sizes) == rgb0.numel() + yuv0.numel()                                # every byte of the frame owned exactly once
+    fb.rgb.zero_(); fb.yuv.zero_()
+    pt.capi.check(lib.pt_fb_unpack_tasks(tr._h, _tasks_c(pt, keep_group), len(keep_group), C.c_void_p(keep.data_ptr()), None))
+    torch.cuda.synchronize()
+    img, ref = fb.rgb_host(), rgb0.cpu().numpy().reshape(H, W, 3)
+    assert np.array_equal(img[H - 30:], ref[H - 30:]) and not img[:H - 30].any()     # rows of tasks 0 and 1 only (offset_y 0 = bottom)
+    fb.rgb.copy_(rgb0); fb.yuv.copy_(yuv0)
+    # single-device gather group: no RCCL involved, the frame reaches the host buffers
+    g = C.c_void_p()
+    devs = (C.c_void_p * 1)(tr._h)
+    pt.capi.check(lib.pt_gather_create(devs, 1, C.byref(g)))
+    host_rgb = np.zeros(rgb0.numel(), np.uint8); host_yuv = np.zeros(yuv0.numel(), np.uint8)
+    owner = (C.c_int * len(ragged))(*([0] * len(ragged)))
+    pt.capi.check(lib.pt_gather_frame(g, _tasks_c(pt, ragged), owner, len(ragged), pt.capi.np_ptr(host_rgb), pt.capi.np_ptr(host_yuv)))
+    assert np.array_equal(host_rgb, rgb0.cpu().numpy()) and np.array_equal(host_yuv, yuv0.cpu().numpy())
+    with pytest.raises(pt.capi.PtError):
+        pt.capi.check(lib.pt_gather_create((C.c_void_p * 2)(tr._h, tr._h), 2, C.byref(C.c_void_p())))      # the same GPU twice
+    pt.capi.check(lib.pt_gather_destroy(g))
+    tr.close()

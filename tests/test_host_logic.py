@@ -583,3 +583,31 @@ def test_missing_native_library_fails_loudly(pt, monkeypatch):
     with pytest.raises(ImportError) as e:
         pt.capi.lib()
     assert "no fallback" in str(e.value)
+
+
+def test_native_exchange_layout_sizes_match_the_python_path(pt):
+    """pt_fb_packed_size (host-only arithmetic of the native gather's layout) against scheduling.packed_size for row
+    bands, and: the rectangles of any partition of a frame own every byte of RGB + YUV420 exactly once."""
+    import ctypes as C
+    lib = pt.capi.lib()
+
+    def size(W, H, tasks):
+        arr = (pt.capi.Task * max(len(tasks), 1))()
+        for i, t in enumerate(tasks):
+            arr[i] = pt.capi.Task(t.width, t.height, t.offset_x, t.offset_y)
+        n = C.c_size_t()
+        pt.capi.check(lib.pt_fb_packed_size(W, H, arr, len(tasks), C.byref(n)))
+        return n.value
+
+    for (W, H, band, world) in [(1920, 1080, 8, 8), (64, 36, 8, 3), (48, 50, 4, 3), (200, 76, 8, 2)]:
+        total = 0
+        for rank in range(world):
+            tasks = pt.row_band_tasks(W, H, band, world, rank)
+            assert size(W, H, tasks) == pt.packed_size(W, H, pt.band_row_ranges(H, band, world, rank))
+            total += size(W, H, tasks)
+        assert total == W * H * 3 + W * H + 2 * (W * H // 4)
+    for n_tasks, in_row in [(4, 2), (8, 2), (6, 3), (16, 4)]:                  # FSFL rectangles (TaskGenerator.h:58-80)
+        layout = pt.get_task_layout(n_tasks, in_row)
+        tasks = pt.TaskGenerator().generateEqualTasks(n_tasks, layout, 1918, 1078)
+        assert sum(size(1918, 1078, [t]) for t in tasks) == 1918 * 1078 * 3 + 1918 * 1078 + 2 * (1918 * 1078 // 4)
+    assert size(64, 64, []) == 0
