@@ -337,16 +337,15 @@ def test_native_pack_equals_python_pack_bands_and_round_trips(pt, box_scene, gpu
     ragged = [pt.RenderTask(37, 30, 0, 0), pt.RenderTask(163, 30, 37, 0), pt.RenderTask(200, 1, 0, 30),
               pt.RenderTask(101, 45, 0, 31), pt.RenderTask(99, 45, 101, 31)]       # a partition of the frame
     sizes = []
-    for group in (ragged[:2], ragged[2:]):
+    for gi, group in enumerate((ragged[:2], ragged[2:])):
         n = C.c_size_t()
         pt.capi.check(lib.pt_fb_packed_size(W, H, _tasks_c(pt, group), len(group), C.byref(n)))
         sizes.append(n.value)
         packed = torch.zeros(n.value, dtype=torch.uint8, device="cuda")
         pt.capi.check(lib.pt_fb_pack_tasks(tr._h, _tasks_c(pt, group), len(group), C.c_void_p(packed.data_ptr()), None))
         torch.cuda.synchronize()
-        if group is ragged[:2]:
-            keep = packed
-            keep_group = group
+        if gi == 0:
+            keep, keep_group = packed, group
     assert sum(sizes) == rgb0.numel() + yuv0.numel()                                # every byte of the frame owned exactly once
     fb.rgb.zero_(); fb.yuv.zero_()
     pt.capi.check(lib.pt_fb_unpack_tasks(tr._h, _tasks_c(pt, keep_group), len(keep_group), C.c_void_p(keep.data_ptr()), None))
