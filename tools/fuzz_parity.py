@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """On the GPU box: randomized parity campaign, HIP path vs the CPU oracle, bit-exact (bytes + counters).
 Random triangle soups (tests/test_gpu_parity.py::_random_scene), random even frame sizes, spp, depth,
-walk schedule, tile schedule, and a random way of covering the frame: one task, a grid of rectangular
-tasks with ragged edges, or single-launch row bands of a random number of ranks.
+walk schedule (the dealt walk with random dealing thresholds / list capacities included), tile schedule, and a random
+way of covering the frame: one task, a grid of rectangular tasks with ragged edges, single-launch row bands of a random
+number of ranks, or the band lists a cost-fed dealer hands out.
 --legacy adds random legacy material kinds and spheres (the pt_set_legacy_scene extension) to half the cases,
 --sah also renders every case with the SAH tree and reports how many images differ (a statistic, not a gate).
 usage: python tools/fuzz_parity.py [first_seed] [count] [--legacy] [--sah]"""
@@ -53,14 +54,18 @@ def one(seed):
         osc.set_legacy(legacy, spheres)
     ref = osc.render(cam, W, H, spp, depth, threads=8)
     info = pt.host_bvh_build(tris)[0]
-    modes = [0, 1, 3] + ([2] if info["nodes"] - info["leaves"] <= 64 else [])
+    small = info["nodes"] - info["leaves"] <= 64
+    modes = [0, 1, 3] + ([2, 4, 4, 4] if small else [])       # 4 = mask walk with dealt sparse leaves (the box's default walk)
     mode = 0 if legacy is not None else int(rng.choice(modes))
+    # the dealt walk's split between dealt and in-place leaves, and its list capacity, are read at pt_device_create
+    os.environ["PTAMD_DEAL_MIN"] = str(int(rng.choice([0, 8, 24, 48, 56, 65])))
+    os.environ["PTAMD_DEAL_CAP"] = str(int(rng.choice([64, 128, 768])))
     fb = pt.Framebuffer(pt.Resolution(W, H))
     tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, pt.CameraConfig(cam[0], cam[1], cam[2], cam[3]),
                              legacyMaterials=legacy, spheres=spheres)
     tr.setTraversalMode(mode)
     tr.setTileSchedule(int(rng.integers(0, 2)))
-    cover = int(rng.integers(0, 3))
+    cover = int(rng.integers(0, 4))
     frames = int(rng.integers(1, 4))                      # later frames run in cost order
     for _ in range(frames):
         fb.rgb.zero_(); fb.yuv.zero_()
@@ -73,10 +78,15 @@ def one(seed):
             for y0, y1 in zip(ys[:-1], ys[1:]):
                 for x0, x1 in zip(xs[:-1], xs[1:]):
                     tr.renderTaskAsync(pt.RenderTask(x1 - x0, y1 - y0, x0, y0))
-        else:
+        elif cover == 2:
             band, world = 2 * int(rng.integers(1, 9)), int(rng.integers(1, 6))
             for r in range(world):
                 tr.renderBandsAsync(band, world, r)
+        else:                                                 # the dynamic dealer's launches: arbitrary band lists
+            band, world = 2 * int(rng.integers(1, 9)), int(rng.integers(1, 6))
+            n_bands = (H + band - 1) // band
+            for l in pt.lpt_assignment([int(v) for v in rng.integers(1, 100, n_bands)], world):
+                tr.renderBandListAsync(band, l)
         tr.waitForRenderTask()
         got = (fb.rgb_host().copy(), fb.yuv_host().copy(), tr.readCounters())
         tgp._assert_same(got, ref)
