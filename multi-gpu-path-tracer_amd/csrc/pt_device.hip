@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
     int x, y, pixel_index;
     const bool in_frame = lane_pixel(P, tid, x, y, pixel_index);
     const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
-    const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
+    const ShadeViewLds V = stage_shade_lds(P, LL.tail, tid, kBlock);      // the host picks this kernel only when the tables fit
     const DealView D = deal_carve(P, V.end, tid, kBlock);
     PathState L;
     path_init(L, P, pixel_index);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
         if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
         if (trace) L.n_seg++;
         const Hit h = traverse_uniform_dealt<kInPlace>(P, D, lane, trace, L.ro, L.rd, 0.001f, 3.402823466e+38f, wave_box, wave_tri);
-        if (trace) shade(L, P, V, h);
+        if (trace) shade<false, ShadeViewLds>(L, P, V, h);
     }
     if (in_frame) write_pixel(P, L.col, pixel_index);
     flush_counters(P, L, lane, wave_box, wave_tri);
@@ -595,7 +595,8 @@ struct pt_device {
 static int choose_walk(const pt_device *d)
 {
     const bool mask_ok = d->n_pairs <= 64, stack_ok = d->n_pairs <= 4096;
-    const bool deal_ok = mask_ok && d->n_tris <= 1024;         // item = lane | slot << 6 in 16 bits
+    // item = lane | slot << 6 in 16 bits; the dealt kernel always stages the shading tables in LDS (fill_params' rule)
+    const bool deal_ok = mask_ok && d->n_tris <= 1024 && (d->n_tris * 48 + d->n_mats * 48 + (size_t)d->n_lights * 80) <= 16 * 1024;
     if (d->legacy_on) return d->force_walk <= 0 ? 0 : -1;      // the extension is compiled into the per-lane walk only
     if (d->sah) return 3;                     // the SAH tree has its own walk
     if (d->force_walk == 0) return 0;

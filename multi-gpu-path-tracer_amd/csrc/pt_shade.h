@@ -122,6 +122,40 @@ struct ShadeView {
     float4 *end;              // first float4 of the workgroup's LDS after the staged tables
 };
 
+// The same tables for a kernel that ALWAYS stages them (the dealt walk: its scenes are small by construction): the
+// pointers carry the LDS address space, so every read is a ds_read_b128.  Through ShadeView's plain pointers -- which may
+// point to LDS or to global memory, decided at launch -- the compiler has to emit FLAT loads, which take the vector-memory
+// path to reach the LDS (that is why the mask-walk profile shows LDS bank-conflict cycles next to almost no LDS
+// instructions: SQ_INSTS_LDS counts ds_* only, the conflicts are those of the flat loads).
+typedef float pt_f4_lds __attribute__((ext_vector_type(4)));
+struct LdsF4 {
+    const __attribute__((address_space(3))) pt_f4_lds *p;
+    __device__ __forceinline__ float4 operator[](size_t i) const { const pt_f4_lds v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ LdsF4 operator+(size_t k) const { LdsF4 r; r.p = p + k; return r; }
+};
+struct ShadeViewLds {
+    LdsF4 shade, mats, lights;
+    float4 *end;
+};
+
+__device__ __forceinline__ ShadeViewLds stage_shade_lds(const RenderParams &P, float4 *lds, int tid, int block)
+{
+    const float4 *gs = reinterpret_cast<const float4 *>(P.shade);
+    const float4 *gm = reinterpret_cast<const float4 *>(P.mats);
+    const float4 *gl = reinterpret_cast<const float4 *>(P.lights);
+    const int ns = P.n_tris * 3, nm = P.n_mats * 3, nl = P.n_lights * 5;
+    for (int i = tid; i < ns; i += block) lds[i] = gs[i];
+    for (int i = tid; i < nm; i += block) lds[ns + i] = gm[i];
+    for (int i = tid; i < nl; i += block) lds[ns + nm + i] = gl[i];
+    __syncthreads();
+    ShadeViewLds V;
+    V.shade.p = (const __attribute__((address_space(3))) pt_f4_lds *)lds;
+    V.mats = V.shade + (size_t)ns;
+    V.lights = V.mats + (size_t)nm;
+    V.end = lds + ns + nm + nl;
+    return V;
+}
+
 __device__ __forceinline__ ShadeView stage_shade(const RenderParams &P, float4 *lds, int tid, int block)
 {
     ShadeView V;
@@ -324,8 +358,8 @@ __device__ __forceinline__ bool legacy_scatter(PathState &L, int kind, v3 albedo
 
 // What camera::ray_color does with the result of one BVH::hit (camera.h:55-80): miss, emissive
 // hit, or a scattering bounce that sets up the next ray segment.
-template <bool kLegacy = false>
-__device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const ShadeView &V, const Hit &h)
+template <bool kLegacy = false, class View = ShadeView>
+__device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const View &V, const Hit &h)
 {
     if (h.slot == -1) {
         L.col = L.col + mk3(0.0f, 0.0f, 0.0f) * L.atten;                // camera.h:78-79
@@ -345,7 +379,7 @@ __device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const
     } else {
         const float4 tc = V.shade[3 * (size_t)h.slot + 2];
         normal = mk3(tc.x, tc.y, tc.z);
-        const float4 *sp4 = V.shade + 3 * (size_t)h.slot;
+        const auto sp4 = V.shade + 3 * (size_t)h.slot;
         s0 = sp4[0]; s1 = sp4[1];
         mat = __float_as_int(s1.z);
     }
@@ -372,7 +406,7 @@ __device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const
             return;
         }
     }
-    const float4 *mp = V.mats + 3 * (size_t)mat;
+    const auto mp = V.mats + 3 * (size_t)mat;
     float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
     int baseTex = __float_as_int(m0.w), emisTex = __float_as_int(m1.w);
     float tu = 0.0f, tv = 0.0f;
@@ -397,7 +431,7 @@ __device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const
     if (xorwow_uniform(L.rng) < 0.5f) {                              // mixture_pdf::generate, pdf.h:66-72
         float uu = xorwow_uniform(L.rng);                            // hitable_list::random, hitable_list.h:23-26
         int idx = (int)truncf((float)((double)uu * P.light_index_scale));
-        const float4 *lp = V.lights + 5 * (size_t)idx;
+        const auto lp = V.lights + 5 * (size_t)idx;
         float4 la = lp[0], ld = lp[3], le = lp[4];
         float r1 = xorwow_uniform(L.rng), r2 = xorwow_uniform(L.rng);  // triangle::random, triangle.h:41-47
         float sq = pt_sqrt(r1);
@@ -417,7 +451,7 @@ __device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const
     // hitable_list::pdf_value, hitable_list.h:16-22 -> triangle::pdf_value, triangle.h:32-40
     float lsum = 0.0f;
     for (int k = 0; k < P.n_lights; k++) {
-        const float4 *lp = V.lights + 5 * (size_t)k;
+        const auto lp = V.lights + 5 * (size_t)k;
         float4 la = lp[0], lb = lp[1], lc = lp[2], le = lp[4];
         v3 v0 = mk3(la.x, la.y, la.z), e1 = mk3(la.w, lb.x, lb.y), e2 = mk3(lb.z, lb.w, lc.x);
         v3 ln = mk3(lc.y, lc.z, lc.w);
