@@ -534,6 +534,7 @@ struct pt_device {
     NodePair *d_nodes = nullptr;
     TriIsect *d_tris = nullptr;
     TriShade *d_shade = nullptr;
+    float4 *d_onb = nullptr;      // onb(normal) per slot, 3 x float4 (small scenes: the dealt kernel's LDS table)
     LightRec *d_lights = nullptr;
     MatRec *d_mats = nullptr;
     TexDesc *d_texs = nullptr;
@@ -624,7 +625,7 @@ static void drop_schedules(pt_device *d)
 
 static void free_scene(pt_device *d)
 {
-    (void)hipFree(d->d_nodes); (void)hipFree(d->d_tris); (void)hipFree(d->d_shade);
+    (void)hipFree(d->d_nodes); (void)hipFree(d->d_tris); (void)hipFree(d->d_shade); (void)hipFree(d->d_onb); d->d_onb = nullptr;
     (void)hipFree(d->d_lights); (void)hipFree(d->d_mats); (void)hipFree(d->d_texs);
     (void)hipFree(d->d_texels); (void)hipFree(d->d_legacy); (void)hipFree(d->d_spheres);
     d->d_legacy = nullptr; d->d_spheres = nullptr; d->n_spheres = 0; d->legacy_on = false;
@@ -900,6 +901,25 @@ try {
     if ((st = upload_vec(pairs, &dev->d_nodes)) != PT_OK) return st;
     if ((st = upload_vec(isect, &dev->d_tris)) != PT_OK) return st;
     if ((st = upload_vec(shade, &dev->d_shade)) != PT_OK) return st;
+    {
+        // onb::onb(normal), onb.h:8-13, per triangle: what shade() would build from the hit's normal on every scattering
+        // bounce.  Only small scenes get the table (it is the dealt kernel's, staged in LDS).
+        std::vector<float4> onb;
+        if (n <= 1024) {
+            onb.resize(3 * n);
+            for (size_t k = 0; k < n; k++) {
+                const v3 nn = mk3(shade[k].nx, shade[k].ny, shade[k].nz);
+                const v3 a2 = normalize(nn);
+                const v3 a = fabsf(a2.x) > 0.9f ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
+                const v3 a1 = normalize(cross(a2, a));
+                const v3 a0 = cross(a2, a1);
+                onb[3 * k] = make_float4(a0.x, a0.y, a0.z, a1.x);
+                onb[3 * k + 1] = make_float4(a1.y, a1.z, a2.x, a2.y);
+                onb[3 * k + 2] = make_float4(a2.z, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        if ((st = upload_vec(onb, &dev->d_onb)) != PT_OK) return st;
+    }
     if ((st = upload_vec(lrec, &dev->d_lights)) != PT_OK) return st;
     if ((st = upload_vec(mrec, &dev->d_mats)) != PT_OK) return st;
     if ((st = upload_vec(tdesc, &dev->d_texs)) != PT_OK) return st;
@@ -1039,13 +1059,14 @@ static size_t lds_bytes(const RenderParams &P, int block, bool stage)
     f4 += ((size_t)P.queue_entries * block * P.queue_dwords + 3) / 4;
     if (P.shade_lds) f4 += (size_t)P.n_tris * 3 + (size_t)P.n_mats * 3 + (size_t)P.n_lights * 5;
     if (P.deal_cap > 0)       // dev::deal_carve
-        f4 += (size_t)P.n_tris * 3 + (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 2 + 15) / 16);
+        f4 += (size_t)P.n_tris * 3 /* onb table, stage_shade_lds */ + (size_t)P.n_tris * 3 +
+              (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 2 + 15) / 16);
     return f4 * 16;
 }
 
 static pt_status fill_params(pt_device *dev, RenderParams &P)
 {
-    P.nodes = dev->d_nodes; P.tris = dev->d_tris; P.shade = dev->d_shade; P.lights = dev->d_lights;
+    P.nodes = dev->d_nodes; P.tris = dev->d_tris; P.shade = dev->d_shade; P.onb = dev->d_onb; P.lights = dev->d_lights;
     P.mats = dev->d_mats; P.texs = dev->d_texs; P.texels = dev->d_texels;
     P.rgb = dev->rgb; P.yuv = dev->yuv; P.counters = dev->d_counters;
     P.n_lights = dev->n_lights;

@@ -15,6 +15,7 @@ struct RenderParams {
     const NodePair *nodes;
     const TriIsect *tris;
     const TriShade *shade;
+    const float4 *onb;                // 3 x float4 per slot {a0, a1, a2, pad}: onb(normal) per triangle (dealt kernel only)
     const LightRec *lights;
     const MatRec *mats;
     const TexDesc *texs;

@@ -27,6 +27,8 @@ __device__ __forceinline__ v3 tex_value(const RenderParams &P, int tex, float u,
 }
 
 struct Onb { v3 a0, a1, a2; };
+struct ShadeView;
+struct ShadeViewLds;
 // onb::onb, onb.h:8-13
 __device__ __forceinline__ Onb onb_make(v3 n)
 {
@@ -135,6 +137,7 @@ struct LdsF4 {
 };
 struct ShadeViewLds {
     LdsF4 shade, mats, lights;
+    LdsF4 onb;                // 3 x float4 per slot: the orthonormal basis of the triangle's normal (onb.h:8-13), precomputed
     float4 *end;
 };
 
@@ -143,16 +146,19 @@ __device__ __forceinline__ ShadeViewLds stage_shade_lds(const RenderParams &P, f
     const float4 *gs = reinterpret_cast<const float4 *>(P.shade);
     const float4 *gm = reinterpret_cast<const float4 *>(P.mats);
     const float4 *gl = reinterpret_cast<const float4 *>(P.lights);
+    const float4 *go = reinterpret_cast<const float4 *>(P.onb);
     const int ns = P.n_tris * 3, nm = P.n_mats * 3, nl = P.n_lights * 5;
     for (int i = tid; i < ns; i += block) lds[i] = gs[i];
     for (int i = tid; i < nm; i += block) lds[ns + i] = gm[i];
     for (int i = tid; i < nl; i += block) lds[ns + nm + i] = gl[i];
+    for (int i = tid; i < ns; i += block) lds[ns + nm + nl + i] = go[i];
     __syncthreads();
     ShadeViewLds V;
     V.shade.p = (const __attribute__((address_space(3))) pt_f4_lds *)lds;
     V.mats = V.shade + (size_t)ns;
     V.lights = V.mats + (size_t)nm;
-    V.end = lds + ns + nm + nl;
+    V.onb = V.lights + (size_t)nl;
+    V.end = lds + 2 * ns + nm + nl;
     return V;
 }
 
@@ -356,6 +362,20 @@ __device__ __forceinline__ bool legacy_scatter(PathState &L, int kind, v3 albedo
     return false;                                                        // diffuse_light: material::scatter
 }
 
+// onb(rec.normal) of a hit: computed on the spot, or -- where the view carries the per-triangle table (the normal of a
+// triangle hit is the triangle's precomputed normal, so its basis is a pure function of the triangle too; the host
+// evaluates the same onb_make with the IEEE forms the device's short forms are proven equal to) -- read from LDS.
+__device__ __forceinline__ Onb hit_onb(const ShadeView &, v3 normal, int) { return onb_make(normal); }
+__device__ __forceinline__ Onb hit_onb(const ShadeViewLds &V, v3 normal, int slot)
+{
+    if (slot < 0) return onb_make(normal);                          // a sphere of the legacy extension (never in this view)
+    const auto q = V.onb + 3 * (size_t)slot;
+    const float4 a = q[0], b = q[1], c = q[2];
+    Onb o;
+    o.a0 = mk3(a.x, a.y, a.z); o.a1 = mk3(a.w, b.x, b.y); o.a2 = mk3(b.z, b.w, c.x);
+    return o;
+}
+
 // What camera::ray_color does with the result of one BVH::hit (camera.h:55-80): miss, emissive
 // hit, or a scattering bounce that sets up the next ray segment.
 template <bool kLegacy = false, class View = ShadeView>
@@ -426,7 +446,7 @@ __device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const
     (void)xorwow_next(L.rng); (void)xorwow_next(L.rng);
     v3 albedo = mk3(m0.x, m0.y, m0.z);
     if (baseTex >= 0) albedo = albedo * tex_value(P, baseTex, tu, tv);
-    Onb uvw = onb_make(normal);                                    // cosine_pdf ctor, pdf.h:15-17
+    const Onb uvw = hit_onb(V, normal, h.slot);                    // cosine_pdf ctor, pdf.h:15-17
     v3 dir;
     if (xorwow_uniform(L.rng) < 0.5f) {                              // mixture_pdf::generate, pdf.h:66-72
         float uu = xorwow_uniform(L.rng);                            // hitable_list::random, hitable_list.h:23-26
