@@ -316,9 +316,10 @@ template <bool kInPlace>
 __device__ __forceinline__ Hit traverse_uniform_dealt(const RenderParams &P, const DealView &D, int lane, bool live, v3 o, v3 d, float tmin,
                                                       float tmax0, unsigned long long &n_box, unsigned long long &n_tri)
 {
-    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
-    uint32_t best_rank = 0;
-    float tmax = tmax0;
+    // The closest hit so far is ONE 64-bit key, t bits << 32 | visit rank << 16 | slot, in the in-place loops as in the
+    // list: "closer, or as close and visited earlier" is a single unsigned compare, and the lane keeps neither the
+    // barycentrics nor a separate t_max (they are recomputed for the winner where a texture needs them).
+    unsigned long long best = ~0ull;
     const v3 inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
     const ConstF4 nodes = as_constant(P.nodes);
     const ConstF4 tris = as_constant(P.tris);
@@ -349,8 +350,8 @@ __device__ __forceinline__ Hit traverse_uniform_dealt(const RenderParams &P, con
                 const uint32_t lanes = (uint32_t)__popcll(hit_mask);
                 n_tri += (unsigned long long)cnt * lanes;
                 if (!kInPlace) {
-                    const uint32_t rank_in = __builtin_amdgcn_mbcnt_hi((uint32_t)(hit_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit_mask, 0u));
                     // every leaf is dealt; a list that cannot take another triangle's pairs is worked off first
+                    const uint32_t rank_in = __builtin_amdgcn_mbcnt_hi((uint32_t)(hit_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit_mask, 0u));
                     any_items = true;
                     uint32_t k0 = 0;
                     while (k0 < cnt) {
@@ -377,27 +378,28 @@ __device__ __forceinline__ Hit traverse_uniform_dealt(const RenderParams &P, con
                     for (uint32_t k = link; k < link + cnt; k++) {
                         const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
                         const float e2z = tris.scalar(3 * k + 2, 0);
-                        const uint32_t krank = __float_as_uint(tris.scalar(3 * k + 2, 1));
+                        const uint32_t low = (__float_as_uint(tris.scalar(3 * k + 2, 1)) << 16) | k;       // rank << 16 | slot, wave-uniform
                         if (hit) {
                             float t, u, v;
-                            if (tri_hit(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, tmin, tmax, t, u, v)) {
-                                tmax = t; h.t = t; h.u = u; h.v = v; h.slot = (int)k; best_rank = krank;
-                            }
+                            const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, t, u, v);
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | low;
+                            if (ok & (t < tmax0) & (t > tmin) & (key < best)) best = key;     // triangle.h:98,100
                         }
                     }
                 }
             }
         }
     }
-    if (!any_items) return h;                            // wave-uniform
-    deal_rounds(D, lane, n_items, tmin, tmax0);
-    const unsigned long long key = D.keys[lane];
-    const unsigned long long mine = (kInPlace && h.slot >= 0) ? (((unsigned long long)__float_as_uint(h.t) << 32) | ((unsigned long long)best_rank << 16) | (uint32_t)h.slot)
-                                                              : ~0ull;
-    if (key < mine) {                                    // a dealt triangle is closer (or as close and visited earlier)
-        h.t = __uint_as_float((uint32_t)(key >> 32));
-        h.slot = (int)(key & 0xffffu);
-        if (D.recompute_uv) {
+    if (any_items) {                                     // wave-uniform
+        deal_rounds(D, lane, n_items, tmin, tmax0);
+        const unsigned long long key = D.keys[lane];
+        if (key < best) best = key;                      // a dealt triangle is closer (or as close and visited earlier)
+    }
+    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+    if (best != ~0ull) {
+        h.t = __uint_as_float((uint32_t)(best >> 32));
+        h.slot = (int)(best & 0xffffu);
+        if (D.recompute_uv) {                            // textured scene: the winner's barycentrics (same arithmetic, same bits)
             const float4 ta = D.tris[3 * h.slot], tb = D.tris[3 * h.slot + 1];
             const float e2z = reinterpret_cast<const float *>(D.tris + 3 * h.slot + 2)[0];
             float t;
