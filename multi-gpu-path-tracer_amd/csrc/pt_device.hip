@@ -266,39 +266,38 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
     extern __shared__ float4 lds_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    int x, y, pixel_index;
-    const bool in_frame = lane_pixel(P, tid, x, y, pixel_index);
+    int x, y;
+    bool in_frame;
+    { int pixel_index; in_frame = lane_pixel(P, tid, x, y, pixel_index); }      // the pixel index is recomputed for the final store
     const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
     const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
     uint32_t *stack = LL.stack + tid;
 
     PathState L;
-    path_init(L, P, pixel_index);
+    { int x0, y0, pixel_index; (void)lane_pixel(P, tid, x0, y0, pixel_index); path_init(L, P, pixel_index); }
     SahWalk W;
     sah_begin(W, mk3(1.0f, 1.0f, 1.0f), 0.0f);
     bool alive = in_frame && P.depth > 0;
-    if (in_frame && P.depth == 0) L.n_paths = (uint32_t)P.spp;      // camera rays are generated, then ray_color returns untraced
     bool walking = false;
     uint32_t cost = 0;                                    // wave-uniform: micro-step trips + 8 per outer trip
-    // Wave totals taken out of the per-lane 32-bit test counters before any of them can wrap (this loop's top is a
-    // convergent point; a lane adds at most one segment's tests between two visits).  Kept wave-uniform, in SGPRs.
-    unsigned long long spill_box = 0, spill_tri = 0;
+    // Work counters of this kernel are WAVE totals in scalar registers: a micro-step trip adds the number of lanes that
+    // take part in it (a popcount of the ballot the majority vote needs anyway) -- no per-lane counter registers, no
+    // per-lane adds, 64 bits wide from the start.
+    unsigned long long wave_box = 0, wave_tri = 0;
+    uint32_t wave_seg = 0;
     while (true) {
         cost += 8;
-        if (__any(((L.n_box | L.n_tri) >> P.fold_bits) != 0)) {
-            spill_box = uniform64(spill_box + wave_sum64(L.n_box));
-            spill_tri = uniform64(spill_tri + wave_sum64(L.n_tri));
-            L.n_box = 0; L.n_tri = 0;
-        }
+        bool begins = false;
         if (alive && !walking) {
             if (L.need_new && !start_path(L, P, x, y)) {
                 alive = false;
             } else {
-                L.n_seg++;
+                begins = true;
                 sah_begin(W, L.rd, 3.402823466e+38f);
                 walking = true;
             }
         }
+        wave_seg += (uint32_t)__popcll(__ballot(begins));
         const int total = __popcll(__ballot(walking));
         if (total == 0) break;                            // wave-uniform: nobody has work left
         while (true) {
@@ -306,19 +305,29 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
             // rather than making the whole wave run its block for a few lanes
             const int want_tri = __popcll(__ballot(walking && W.n0 != 0));
             const int want_node = __popcll(__ballot(walking && W.n0 == 0));
+            uint32_t unused = 0;
             if (want_tri >= want_node) {
-                if (walking && W.n0 != 0) walking = sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
+                wave_tri += (uint32_t)want_tri;
+                if (walking && W.n0 != 0) walking = sah_tri_step(P, W, L.ro, L.rd, 0.001f, unused);
             } else {
-                if (walking && W.n0 == 0) walking = sah_node_step(P, W, L.ro, L.rd, stack, kBlock, L.n_box);
+                wave_box += 2u * (uint32_t)want_node;
+                if (walking && W.n0 == 0) walking = sah_node_step(P, W, L.ro, L.rd, stack, kBlock, unused);
             }
             const int still = __popcll(__ballot(walking));
             cost++;
             if (still * 100 <= total * P.spec_pct) break;
         }
-        if (alive && !walking) shade(L, P, V, W.h);
+        if (alive && !walking) shade(L, P, V, sah_hit(P, W, L.ro, L.rd));
     }
-    if (in_frame) write_pixel(P, L.col, pixel_index);
-    flush_counters(P, L, lane, spill_box, spill_tri);
+    {
+        int x0, y0, pixel_index;
+        (void)lane_pixel(P, tid, x0, y0, pixel_index);
+        if (in_frame) write_pixel(P, L.col, pixel_index);
+    }
+    // paths = samples started (all of them when depth == 0: camera rays are generated, then ray_color returns untraced)
+    L.n_paths = in_frame ? (P.depth == 0 ? (uint32_t)P.spp : (uint32_t)L.s) : 0u;
+    L.n_seg = 0; L.n_box = 0; L.n_tri = 0; L.box_hi = 0; L.tri_hi = 0;
+    flush_counters(P, L, lane, wave_box, wave_tri, wave_seg);
     record_tile_cost(P, tid, cost);
 }
 
@@ -553,6 +562,7 @@ struct pt_device {
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
     int spec_pct = 50;            // ... and leaves the walk loop when <= this % of the walkers remain
     int deal_cap = 768, deal_min = 48;   // dealt walk (kWalk 4): item list capacity per wave; in-place threshold (lanes)
+    int sah_waves = 0;            // SAH kernel build: 0 = by scene size, 5 / 6 = force (PTAMD_SAH_WAVES, A/B runs)
     int lrpt = 0;                 // dealt kernel: issue priority by remaining samples (PTAMD_LRPT)
     bool deal_auto = true;        // automatic choice prefers the dealt walk over the plain mask walk (PTAMD_DEAL=0: off)
     bool any_tex = false;
@@ -677,6 +687,7 @@ try {
     if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 100) d->spec_pct = v; }
     if (const char *e = getenv("PTAMD_DEAL")) d->deal_auto = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_LRPT")) d->lrpt = atoi(e) != 0;
+    if (const char *e = getenv("PTAMD_SAH_WAVES")) { const int v = atoi(e); if (v == 5 || v == 6) d->sah_waves = v; }
     if (const char *e = getenv("PTAMD_DEAL_MIN")) { const int v = atoi(e); if (v >= 0 && v <= 65) d->deal_min = v; }
     if (const char *e = getenv("PTAMD_DEAL_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 8192) d->deal_cap = v & ~7; }
     if (const char *e = getenv("PTAMD_FOLD_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 31) d->fold_bits = v; }
@@ -1146,7 +1157,8 @@ static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool 
 {
     if (walk == 3 && dev->sah_persistent) {
         const size_t scene_bytes = dev->n_pairs * sizeof(NodePair) + dev->n_tris * sizeof(TriIsect);
-        return scene_bytes <= ((size_t)64 << 20) ? PT_KERNEL(dev::render_kernel_sah6) : PT_KERNEL(dev::render_kernel_sah);
+        const bool six = dev->sah_waves == 6 || (dev->sah_waves == 0 && scene_bytes <= ((size_t)64 << 20));
+        return six ? PT_KERNEL(dev::render_kernel_sah6) : PT_KERNEL(dev::render_kernel_sah);
     }
     if (walk == 3) return PT_KERNEL(dev::render_kernel<false, true, 3>);
     if (walk == 1) return PT_KERNEL(dev::render_kernel<false, true, 1>);

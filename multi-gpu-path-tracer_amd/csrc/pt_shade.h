@@ -526,9 +526,9 @@ __device__ __forceinline__ void write_pixel(const RenderParams &P, v3 col, int p
 // wave_box / wave_tri: totals a wave-uniform walk (traverse_uniform, traverse_uniform_stack) kept for the whole
 // wave.  A lane stops adding to its copy when its pixel is done, so the lane that ran longest holds the total.
 __device__ __forceinline__ void flush_counters(const RenderParams &P, const PathState &L, int lane,
-                                               unsigned long long wave_box = 0, unsigned long long wave_tri = 0)
+                                               unsigned long long wave_box = 0, unsigned long long wave_tri = 0, uint32_t wave_seg = 0)
 {
-    const uint32_t c0 = wave_sum(L.n_paths), c1 = wave_sum(L.n_seg), c4 = wave_sum(L.n_light);
+    const uint32_t c0 = wave_sum(L.n_paths), c1 = wave_sum(L.n_seg) + wave_seg, c4 = wave_sum(L.n_light);
     const unsigned long long lane_box = (unsigned long long)L.n_box + ((unsigned long long)L.box_hi << P.fold_bits);
     const unsigned long long lane_tri = (unsigned long long)L.n_tri + ((unsigned long long)L.tri_hi << P.fold_bits);
     const unsigned long long c2 = wave_sum64(lane_box) + wave_max64(wave_box), c3 = wave_sum64(lane_tri) + wave_max64(wave_tri);

@@ -505,10 +505,12 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
 struct SahWalk {
     uint32_t pair;
     int sp;
-    float tbest;
+    float tbest;                  // t of the closest hit so far (the segment's t_max while there is none)
     uint32_t best_rank;
+    int best_slot;                // its leaf-order slot, -1 = none.  The barycentrics are not carried along the walk
+                                  // (two registers and two selects per triangle test): sah_hit() recomputes them for
+                                  // the winner, with the same arithmetic on the same operands -> the same bits
     v3 inv;
-    Hit h;
     uint32_t k0, n0, k1, n1;      // pending leaf triangles: range 0 first, then range 1
     bool more_nodes;              // `pair` still has to be visited
 };
@@ -517,7 +519,7 @@ __device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
 {
     W.pair = 0; W.sp = 0; W.tbest = tmax0; W.best_rank = 0xFFFFFFFFu;
     W.inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
-    W.h.t = 0.0f; W.h.u = 0.0f; W.h.v = 0.0f; W.h.slot = -1;
+    W.best_slot = -1;
     W.k0 = W.n0 = W.k1 = W.n1 = 0;
     W.more_nodes = true;
 }
@@ -540,7 +542,7 @@ __device__ __forceinline__ bool sah_tri_step(const RenderParams &P, SahWalk &W, 
         const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d, t, u, v);
         const uint32_t rank = __float_as_uint(tc.y);
         if (ok & (t > tmin) & ((t < W.tbest) | ((t == W.tbest) & (rank < W.best_rank)))) {
-            W.tbest = t; W.best_rank = rank; W.h.t = t; W.h.u = u; W.h.v = v; W.h.slot = (int)W.k0;
+            W.tbest = t; W.best_rank = rank; W.best_slot = (int)W.k0;
         }
         W.k0++; W.n0--;
         if (W.n0 == 0) { W.k0 = W.k1; W.n0 = W.n1; W.n1 = 0; }
@@ -596,6 +598,23 @@ __device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W,
     return W.n0 != 0 || W.more_nodes;
 }
 
+// The finished walk's hit record.  want_uv: the scene has textures (the only reader of the barycentrics, pt_shade.h).
+__device__ __forceinline__ Hit sah_hit(const RenderParams &P, const SahWalk &W, v3 o, v3 d)
+{
+    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = W.best_slot;
+    if (W.best_slot >= 0) {
+        h.t = W.tbest;
+        if (P.any_tex) {
+            const float4 *tp = reinterpret_cast<const float4 *>(P.tris) + 3 * (size_t)W.best_slot;
+            const float4 ta = tp[0], tb = tp[1];
+            const float e2z = reinterpret_cast<const float *>(tp + 2)[0];
+            float t;
+            (void)mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, t, h.u, h.v);
+        }
+    }
+    return h;
+}
+
 __device__ __forceinline__ bool sah_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin,
                                          uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
 {
@@ -609,7 +628,7 @@ __device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, f
     SahWalk W;
     sah_begin(W, d, tmax0);
     while (sah_step(P, W, o, d, tmin, stack, stride, n_box, n_tri)) {}
-    return W.h;
+    return sah_hit(P, W, o, d);
 }
 
 } // namespace dev
