@@ -139,12 +139,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
     PathState L;
     path_init(L, P, pixel_index);
     bool alive = in_frame && P.depth > 0;
-    if (in_frame && P.depth == 0) L.n_paths = (uint32_t)P.spp;
+    // wave totals in scalar registers: box / triangle tests (as in the mask walk), segments (lanes that trace in a trip)
+    // and the trip count itself, which is this tile's cost for the next launch's order
     unsigned long long wave_box = 0, wave_tri = 0;
-    // Issue priority by remaining work (P.lrpt).  The SIMD arbitrates VALU issue by priority, then AGE: left alone, the
-    // oldest wave of a SIMD runs almost unimpeded and the youngest starves, so when the launch's queue runs dry a SIMD
-    // works its last waves off one after the other and ends on a lone wave at half the issue rate.  A wave that still
-    // has most of its samples ahead outranks one that is nearly done: the waves of a SIMD then finish together.
+    uint32_t wave_seg = 0, trips = 0;
+    // Issue priority by remaining work (P.lrpt; measured neutral): a wave that still has most of its samples
+    // ahead outranks one that is nearly done.
     int prio_now = 0;
     while (true) {
         const unsigned long long alive_mask = __ballot(alive);
@@ -163,13 +163,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
         }
         bool trace = alive;
         if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
-        if (trace) L.n_seg++;
+        const unsigned long long trace_mask = __ballot(trace);
+        if (trace_mask != 0ull) {                          // (the last trip of a wave only discovers that every pixel is done)
+            wave_seg += (uint32_t)__popcll(trace_mask);
+            trips++;
+        }
         const Hit h = traverse_uniform_dealt<kInPlace>(P, D, lane, trace, L.ro, L.rd, 0.001f, 3.402823466e+38f, wave_box, wave_tri);
         if (trace) shade<false, ShadeViewLds>(L, P, V, h);
     }
     if (in_frame) write_pixel(P, L.col, pixel_index);
-    flush_counters(P, L, lane, wave_box, wave_tri);
-    record_tile_cost(P, tid, wave_max(L.n_seg));
+    L.n_paths = in_frame ? (P.depth == 0 ? (uint32_t)P.spp : (uint32_t)L.s) : 0u;      // samples started (depth 0: rays generated, untraced)
+    L.n_seg = 0;
+    flush_counters(P, L, lane, wave_box, wave_tri, wave_seg);
+    record_tile_cost(P, tid, trips);
 #ifdef PT_TIMELINE
     {
         const uint32_t slot = blockIdx.x * kWavesPerBlock + tid / kWave;
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
             g_timeline[4 * slot] = tl_start;
             g_timeline[4 * slot + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
             g_timeline[4 * slot + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));                       // HW_ID
-            g_timeline[4 * slot + 3] = (wave_max(L.n_seg) & 0xffffu) | (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16);   // cost | XCC_ID << 16
+            g_timeline[4 * slot + 3] = (trips & 0xffffu) | (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16);   // cost | XCC_ID << 16
         }
     }
 #endif
