@@ -365,3 +365,58 @@ def test_native_pack_equals_python_pack_bands_and_round_trips(pt, box_scene, gpu
         pt.capi.check(lib.pt_gather_create((C.c_void_p * 2)(tr._h, tr._h), 2, C.byref(C.c_void_p())))      # the same GPU twice
     pt.capi.check(lib.pt_gather_destroy(g))
     tr.close()
+
+
+def test_full_size_c5_properties(pt, box_scene, gpu_device):
+    """BASELINE.json configs[4] (3840x2160, 1024 spp, 16 bounces; ~0.9 s per frame) is far beyond the oracle: exact
+    path count, determinism across two launches (raster order, then cost order), and the union of the band lists a
+    cost-fed dealer hands 8 ranks == the whole frame, bytes and every counter."""
+    W, H, spp, depth = 3840, 2160, 1024, 16
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
+
+    def frame(launch):
+        fb.rgb.zero_(); fb.yuv.zero_()
+        tr.resetCounters()
+        launch()
+        tr.waitForRenderTask()
+        return hashlib.sha256(fb.rgb_host().tobytes() + fb.yuv_host().tobytes()).hexdigest(), tr.readCounters()
+
+    h1, c1 = frame(lambda: tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)))
+    assert c1["paths"] == W * H * spp and 2.0 < c1["segments"] / c1["paths"] < 3.2
+    assert (h1, c1) == frame(lambda: tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)))
+    tr.renderBandListAsync(8, list(range(270))); tr.waitForRenderTask()
+    lists = pt.lpt_assignment(tr.bandCosts(), 8)
+    assert sorted(b for l in lists for b in l) == list(range(270))
+
+    def dealt():
+        for l in lists:
+            tr.renderBandListAsync(8, l)
+    assert (h1, c1) == frame(dealt)
+    tr.close()
+
+
+def test_bench_line_contract(gpu_device):
+    """bench.py prints ONE JSON line the driver parses: the contract's keys, a roofline block whose fraction is a
+    fraction (or null when no profile of this build is committed), the CPU baseline with the cores it used."""
+    import json
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--steps", "3", "--warmup", "1",
+                          "--cpu-rows", "16"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "ray-segments/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f32"
+    assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("valu-issue", "hbm") and r["peak"] > 0 and r["kernel_ms_avg"] > 0 and r["launches"] == 3
+    assert r["frac"] is None or 0 < r["frac"] <= 1
+    assert (r["achieved"] is None) == (r["frac"] is None)
+    assert "render_kernel" in r["kernel"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["host_cpu_count"] >= c["cores"]
+    assert d["value"] > 100 * c["value"] / c["cores"]                 # a GPU, not a fallback
