@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
     // ahead outranks one that is nearly done.
     int prio_now = 0;
     while (true) {
-        const unsigned long long alive_mask = __ballot(alive);
+        const unsigned long long alive_mask = pt_ballot(alive);
         if (alive_mask == 0ull) break;
         if (P.lrpt) {
             const int s_now = __builtin_amdgcn_readlane(L.s, (int)__builtin_ctzll(alive_mask));     // a tile's pixels progress within a few %
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
         }
         bool trace = alive;
         if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
-        const unsigned long long trace_mask = __ballot(trace);
+        const unsigned long long trace_mask = pt_ballot(trace);
         if (trace_mask != 0ull) {                          // (the last trip of a wave only discovers that every pixel is done)
             wave_seg += (uint32_t)__popcll(trace_mask);
             trips++;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
     // per trip; trip n+1 writes the other buffer, and by the time buffer n is written again (trip n+2) every
     // wave has passed the barrier of trip n+1, i.e. has finished reading it.
     int buf = 0;
-    while (__any(alive)) {
+    while (pt_any(alive)) {
         bool trace = alive;
         if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
         Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
@@ -283,48 +283,49 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
     { int x0, y0, pixel_index; (void)lane_pixel(P, tid, x0, y0, pixel_index); path_init(L, P, pixel_index); }
     SahWalk W;
     sah_begin(W, mk3(1.0f, 1.0f, 1.0f), 0.0f);
+    W.pair = kNoPair;                                      // nobody walks yet
     bool alive = in_frame && P.depth > 0;
-    bool walking = false;
     uint32_t cost = 0;                                    // wave-uniform: micro-step trips + 8 per outer trip
     // Work counters of this kernel are WAVE totals in scalar registers: a micro-step trip adds the number of lanes that
     // take part in it (a popcount of the ballot the majority vote needs anyway) -- no per-lane counter registers, no
-    // per-lane adds, 64 bits wide from the start.
-    unsigned long long wave_box = 0, wave_tri = 0;
-    uint32_t wave_seg = 0;
+    // per-lane adds.  32-bit halves with an explicit carry keep every compare and add on the scalar unit.
+    uint32_t box_lo = 0, box_hi = 0, tri_lo = 0, tri_hi = 0, wave_seg = 0;
     while (true) {
         cost += 8;
         bool begins = false;
-        if (alive && !walking) {
+        if (alive && !sah_walking(W)) {
             if (L.need_new && !start_path(L, P, x, y)) {
                 alive = false;
             } else {
                 begins = true;
                 sah_begin(W, L.rd, 3.402823466e+38f);
-                walking = true;
             }
         }
-        wave_seg += (uint32_t)__popcll(__ballot(begins));
-        const int total = __popcll(__ballot(walking));
+        wave_seg += (uint32_t)__popcll(pt_ballot(begins));
+        const uint32_t total = (uint32_t)__popcll(pt_ballot(W.n0 != 0) | pt_ballot(W.pair != kNoPair));
         if (total == 0) break;                            // wave-uniform: nobody has work left
         while (true) {
             // one kind of micro-step per trip, chosen by majority vote: the minority waits a trip
             // rather than making the whole wave run its block for a few lanes
-            const int want_tri = __popcll(__ballot(walking && W.n0 != 0));
-            const int want_node = __popcll(__ballot(walking && W.n0 == 0));
+            const unsigned long long tri_mask = pt_ballot(W.n0 != 0), pair_mask = pt_ballot(W.pair != kNoPair);
+            const uint32_t want_tri = (uint32_t)__popcll(tri_mask), want_node = (uint32_t)__popcll(pair_mask & ~tri_mask);
             uint32_t unused = 0;
             if (want_tri >= want_node) {
-                wave_tri += (uint32_t)want_tri;
-                if (walking && W.n0 != 0) walking = sah_tri_step(P, W, L.ro, L.rd, 0.001f, unused);
+                tri_lo += want_tri;
+                if (tri_lo >> 31) { tri_lo -= 1u << 31; tri_hi++; }
+                if (sah_wants_tri(W)) (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, unused);
             } else {
-                wave_box += 2u * (uint32_t)want_node;
-                if (walking && W.n0 == 0) walking = sah_node_step(P, W, L.ro, L.rd, stack, kBlock, unused);
+                box_lo += 2u * want_node;
+                if (box_lo >> 31) { box_lo -= 1u << 31; box_hi++; }
+                if (sah_wants_node(W)) (void)sah_node_step(P, W, L.ro, L.rd, stack, kBlock, unused);
             }
-            const int still = __popcll(__ballot(walking));
+            const uint32_t still = (uint32_t)__popcll(pt_ballot(W.n0 != 0) | pt_ballot(W.pair != kNoPair));
             cost++;
-            if (still * 100 <= total * P.spec_pct) break;
+            if (still * 100u <= total * (uint32_t)P.spec_pct) break;
         }
-        if (alive && !walking) shade(L, P, V, sah_hit(P, W, L.ro, L.rd));
+        if (alive && !sah_walking(W)) shade(L, P, V, sah_hit(P, W, L.ro, L.rd));
     }
+    const unsigned long long wave_box = ((unsigned long long)box_hi << 31) + box_lo, wave_tri = ((unsigned long long)tri_hi << 31) + tri_lo;
     {
         int x0, y0, pixel_index;
         (void)lane_pixel(P, tid, x0, y0, pixel_index);

@@ -28,6 +28,11 @@ namespace pt {
 // both on the GPU (pt_kat_exhaustive, tests/test_gpu_parity.py) -- at under half the instructions of
 // the compiler's division sequence (v_div_scale x2, v_rcp, 5 fma/mul, v_div_fmas, v_div_fixup).
 #if defined(__HIPCC__)
+// Wave votes on a bool.  HIP's __ballot / __any take an int: the bool is first materialised as 0 / 1 in a VGPR
+// (v_cndmask) and compared with zero again (v_cmp_ne) -- two VALU instructions per vote that these forms do not need
+// (the condition already is a lane mask in SGPRs).  The walks vote several times per trip.
+__device__ __forceinline__ unsigned long long pt_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool pt_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // v_rcp (1 ulp) + one Newton step in FMA + v_div_fixup (zeros, infinities, NaN).  Measured exhaustively:
 // equals 1.0f/x for every x with 2^-126 <= |x| <= 2^126 and for +-0, +-inf, NaN; it is wrong only for
 // (some) denormal x and for |x| > 2^126 (denormal quotient), which the callers below route to the
@@ -43,14 +48,14 @@ __device__ __forceinline__ float pt_rcp(float x)                                
 {
     float r = pt_rcp_core(x);
     const bool odd = __builtin_amdgcn_classf(x, 0x90) | (__builtin_fabsf(x) > 0x1p126f);   // 0x90: +-denormal
-    if (__builtin_expect(__any(odd), 0)) r = 1.0f / x;      // wave-uniform branch, practically never taken
+    if (__builtin_expect(pt_any(odd), 0)) r = 1.0f / x;      // wave-uniform branch, practically never taken
     return r;
 }
 // Same, for a caller that discards the result whenever |x| <= 1e-8 (Moller-Trumbore's det).
 __device__ __forceinline__ float pt_rcp_not_tiny(float x)
 {
     float r = pt_rcp_core(x);
-    if (__builtin_expect(__any(__builtin_fabsf(x) > 0x1p126f), 0)) r = 1.0f / x;
+    if (__builtin_expect(pt_any(__builtin_fabsf(x) > 0x1p126f), 0)) r = 1.0f / x;
     return r;
 }
 // v_rsq (1 ulp) -> s = x*y, h = y/2, one residual step s + (x - s*s)*h in FMA.  Measured exhaustively:
@@ -64,7 +69,7 @@ __device__ __forceinline__ float pt_sqrt(float x)                               
     float r = __builtin_fmaf(-s, s, x);
     s = __builtin_fmaf(r, h, s);
     const bool odd = !((x >= 0x1p-100f) & (x <= 3.402823466e+38f));
-    if (__builtin_expect(__any(odd), 0)) s = sqrtf(x);
+    if (__builtin_expect(pt_any(odd), 0)) s = sqrtf(x);
     return s;
 }
 // x * (1/pi) in double, one FMA residual correction, round to float: equals the double division's

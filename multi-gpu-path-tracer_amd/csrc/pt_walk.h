@@ -223,7 +223,7 @@ __device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 
     const int n_pairs = P.n_pairs;
     for (int p = 0; p < n_pairs; p++) {
         const bool on = (act >> p) & 1ull;
-        const unsigned long long on_mask = __ballot(on);
+        const unsigned long long on_mask = pt_ballot(on);
         if (on_mask == 0ull) continue;                   // nobody in the wave visits pair p
         const float4 a = nodes[4 * p], b = nodes[4 * p + 1], c = nodes[4 * p + 2], lf = nodes[4 * p + 3];
         const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
@@ -237,7 +237,7 @@ __device__ __forceinline__ Hit traverse_uniform(const RenderParams &P, v3 o, v3 
             const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
             if (cnt == 0) {                              // inner child: mark its pair
                 if (hit) act |= 1ull << link;
-            } else if (const unsigned long long hit_mask = __ballot(hit)) {   // leaf child somebody hits
+            } else if (const unsigned long long hit_mask = pt_ballot(hit)) {   // leaf child somebody hits
                 n_tri += (unsigned long long)cnt * (uint32_t)__popcll(hit_mask);
                 for (uint32_t k = link; k < link + cnt; k++) {
                     const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
@@ -332,7 +332,7 @@ __device__ __forceinline__ Hit traverse_uniform_dealt(const RenderParams &P, con
     const int n_pairs = P.n_pairs;
     for (int p = 0; p < n_pairs; p++) {
         const bool on = (act >> p) & 1ull;
-        const unsigned long long on_mask = __ballot(on);
+        const unsigned long long on_mask = pt_ballot(on);
         if (on_mask == 0ull) continue;
         const float4 a = nodes[4 * p], b = nodes[4 * p + 1], c = nodes[4 * p + 2], lf = nodes[4 * p + 3];
         const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
@@ -346,7 +346,7 @@ __device__ __forceinline__ Hit traverse_uniform_dealt(const RenderParams &P, con
             const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
             if (cnt == 0) {
                 if (hit) act |= 1ull << link;
-            } else if (const unsigned long long hit_mask = __ballot(hit)) {
+            } else if (const unsigned long long hit_mask = pt_ballot(hit)) {
                 const uint32_t lanes = (uint32_t)__popcll(hit_mask);
                 n_tri += (unsigned long long)cnt * lanes;
                 if (!kInPlace) {
@@ -437,9 +437,9 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
     const int n_pairs = P.n_pairs;
     for (int p = 0; p < n_pairs; p++) {
         const bool on = walking && next == (uint32_t)p;
-        const unsigned long long on_mask = __ballot(on);
+        const unsigned long long on_mask = pt_ballot(on);
         if (on_mask == 0ull) {
-            if (__ballot(walking) == 0ull) break;        // every lane of the wave is done
+            if (pt_ballot(walking) == 0ull) break;        // every lane of the wave is done
             continue;
         }
         const float4 a = nodes[4 * p], b = nodes[4 * p + 1], c = nodes[4 * p + 2], lf = nodes[4 * p + 3];
@@ -467,7 +467,7 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
         for (int side = 0; side < 2; side++) {
             const bool hit = side ? hr : hl;
             const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
-            const unsigned long long hit_mask = cnt != 0 ? __ballot(hit) : 0ull;
+            const unsigned long long hit_mask = cnt != 0 ? pt_ballot(hit) : 0ull;
             if (hit_mask != 0ull) {
                 uint32_t k0 = link, k1 = link + cnt;
                 if (kParts > 1) {
@@ -512,8 +512,14 @@ struct SahWalk {
                                   // the winner, with the same arithmetic on the same operands -> the same bits
     v3 inv;
     uint32_t k0, n0, k1, n1;      // pending leaf triangles: range 0 first, then range 1
-    bool more_nodes;              // `pair` still has to be visited
+    // `pair` == kNoPair: no node is left to visit.  (A register compare a vote can use directly: a bool carried across
+    // trips is materialised as 0 / 1 and compared again for every ballot.)
 };
+constexpr uint32_t kNoPair = 0xFFFFFFFFu;
+// What a lane of the SAH walk wants next: a triangle test, a node visit, or nothing (walk complete).
+__device__ __forceinline__ bool sah_wants_tri(const SahWalk &W) { return W.n0 != 0; }
+__device__ __forceinline__ bool sah_wants_node(const SahWalk &W) { return (W.n0 == 0) & (W.pair != kNoPair); }
+__device__ __forceinline__ bool sah_walking(const SahWalk &W) { return (W.n0 != 0) | (W.pair != kNoPair); }
 
 __device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
 {
@@ -521,7 +527,6 @@ __device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
     W.inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
     W.best_slot = -1;
     W.k0 = W.n0 = W.k1 = W.n1 = 0;
-    W.more_nodes = true;
 }
 
 // One MICRO-step of the SAH walk: either one Moller-Trumbore test (if this lane has leaf triangles
@@ -546,7 +551,7 @@ __device__ __forceinline__ bool sah_tri_step(const RenderParams &P, SahWalk &W, 
         }
         W.k0++; W.n0--;
         if (W.n0 == 0) { W.k0 = W.k1; W.n0 = W.n1; W.n1 = 0; }
-        return W.n0 != 0 || W.more_nodes;
+        return sah_walking(W);
     }
 }
 
@@ -590,12 +595,12 @@ __device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W,
     } else if (gl || gr) {
         W.pair = gl ? llink : rlink;
     } else if (W.sp == 0) {
-        W.more_nodes = false;
+        W.pair = kNoPair;
     } else {
         W.sp--;
         W.pair = stack[W.sp * stride];
     }
-    return W.n0 != 0 || W.more_nodes;
+    return sah_walking(W);
 }
 
 // The finished walk's hit record.  want_uv: the scene has textures (the only reader of the barycentrics, pt_shade.h).
