@@ -286,12 +286,13 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
     W.pair = kNoPair;                                      // nobody walks yet
     bool alive = in_frame && P.depth > 0;
     uint32_t cost = 0;                                    // wave-uniform: micro-step trips + 8 per outer trip
-    // Work counters of this kernel are WAVE totals in scalar registers: a micro-step trip adds the number of lanes that
-    // take part in it (a popcount of the ballot the majority vote needs anyway) -- no per-lane counter registers, no
-    // per-lane adds.  32-bit halves with an explicit carry keep every compare and add on the scalar unit.
-    uint32_t box_lo = 0, box_hi = 0, tri_lo = 0, tri_hi = 0, wave_seg = 0;
+    // Box / triangle tests are counted per lane (one masked add per micro-step; a wave-level sum of the vote's popcounts
+    // was tried: the compiler keeps such a loop-carried uniform sum in vector registers and spends four instructions per
+    // trip on its carry) and folded into wider per-lane words once per outer trip, long before 32 bits can wrap.
+    uint32_t wave_seg = 0;
     while (true) {
         cost += 8;
+        fold_counters(L, P.fold_bits);
         bool begins = false;
         if (alive && !sah_walking(W)) {
             if (L.need_new && !start_path(L, P, x, y)) {
@@ -301,31 +302,25 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
                 sah_begin(W, L.rd, 3.402823466e+38f);
             }
         }
-        wave_seg += (uint32_t)__popcll(pt_ballot(begins));
-        const uint32_t total = (uint32_t)__popcll(pt_ballot(W.n0 != 0) | pt_ballot(W.pair != kNoPair));
+        wave_seg += (uint32_t)__builtin_popcountll(pt_ballot(begins));
+        const uint32_t total = (uint32_t)pt_popc(pt_ballot(W.n0 != 0) | pt_ballot(W.pair != kNoPair));
         if (total == 0) break;                            // wave-uniform: nobody has work left
         while (true) {
             // one kind of micro-step per trip, chosen by majority vote: the minority waits a trip
             // rather than making the whole wave run its block for a few lanes
             const unsigned long long tri_mask = pt_ballot(W.n0 != 0), pair_mask = pt_ballot(W.pair != kNoPair);
-            const uint32_t want_tri = (uint32_t)__popcll(tri_mask), want_node = (uint32_t)__popcll(pair_mask & ~tri_mask);
-            uint32_t unused = 0;
+            const int want_tri = pt_popc(tri_mask), want_node = pt_popc(pair_mask & ~tri_mask);
             if (want_tri >= want_node) {
-                tri_lo += want_tri;
-                if (tri_lo >> 31) { tri_lo -= 1u << 31; tri_hi++; }
-                if (sah_wants_tri(W)) (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, unused);
+                if (sah_wants_tri(W)) (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
             } else {
-                box_lo += 2u * want_node;
-                if (box_lo >> 31) { box_lo -= 1u << 31; box_hi++; }
-                if (sah_wants_node(W)) (void)sah_node_step(P, W, L.ro, L.rd, stack, kBlock, unused);
+                if (sah_wants_node(W)) (void)sah_node_step(P, W, L.ro, L.rd, stack, kBlock, L.n_box);
             }
-            const uint32_t still = (uint32_t)__popcll(pt_ballot(W.n0 != 0) | pt_ballot(W.pair != kNoPair));
+            const uint32_t still = (uint32_t)pt_popc(pt_ballot(W.n0 != 0) | pt_ballot(W.pair != kNoPair));
             cost++;
             if (still * 100u <= total * (uint32_t)P.spec_pct) break;
         }
         if (alive && !sah_walking(W)) shade(L, P, V, sah_hit(P, W, L.ro, L.rd));
     }
-    const unsigned long long wave_box = ((unsigned long long)box_hi << 31) + box_lo, wave_tri = ((unsigned long long)tri_hi << 31) + tri_lo;
     {
         int x0, y0, pixel_index;
         (void)lane_pixel(P, tid, x0, y0, pixel_index);
@@ -333,8 +328,8 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
     }
     // paths = samples started (all of them when depth == 0: camera rays are generated, then ray_color returns untraced)
     L.n_paths = in_frame ? (P.depth == 0 ? (uint32_t)P.spp : (uint32_t)L.s) : 0u;
-    L.n_seg = 0; L.n_box = 0; L.n_tri = 0; L.box_hi = 0; L.tri_hi = 0;
-    flush_counters(P, L, lane, wave_box, wave_tri, wave_seg);
+    L.n_seg = 0;
+    flush_counters(P, L, lane, 0ull, 0ull, wave_seg);
     record_tile_cost(P, tid, cost);
 }
 

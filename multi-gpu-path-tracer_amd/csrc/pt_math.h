@@ -33,6 +33,15 @@ namespace pt {
 // (the condition already is a lane mask in SGPRs).  The walks vote several times per trip.
 __device__ __forceinline__ unsigned long long pt_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool pt_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// Population count of a lane mask as a 32-bit scalar.  Through __builtin_popcountll the compiler compares two such counts
+// as 64-bit values, for which the scalar unit has no ordered compare: it moves one of them into a vector register and
+// compares there (v_mov + v_cmp_lt_u64 + s_and with exec) on every vote.
+__device__ __forceinline__ int pt_popc(unsigned long long mask)
+{
+    int r;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(r) : "s"(mask) : "scc");
+    return r;
+}
 // v_rcp (1 ulp) + one Newton step in FMA + v_div_fixup (zeros, infinities, NaN).  Measured exhaustively:
 // equals 1.0f/x for every x with 2^-126 <= |x| <= 2^126 and for +-0, +-inf, NaN; it is wrong only for
 // (some) denormal x and for |x| > 2^126 (denormal quotient), which the callers below route to the
