@@ -872,7 +872,16 @@ try {
             }
         }
     }
-    if (sah) pairs = sahbvh.pairs;
+    if (sah) {
+        // the SAH walk addresses records by 32-bit byte offsets (pt_walk.h SahWalk): scale the builder's links
+        if (n * sizeof(TriIsect) >= ((size_t)1 << 32) || sahbvh.pairs.size() * sizeof(NodePair) >= ((size_t)1 << 32))
+            return set_error(PT_ERR_UNSUPPORTED, "SAH tree: node and triangle records are addressed by 32-bit byte offsets (< 89 M triangles)");
+        pairs = sahbvh.pairs;
+        for (NodePair &q : pairs) {
+            q.llink *= q.lcnt ? (uint32_t)sizeof(TriIsect) : (uint32_t)sizeof(NodePair);
+            q.rlink *= q.rcnt ? (uint32_t)sizeof(TriIsect) : (uint32_t)sizeof(NodePair);
+        }
+    }
     const std::vector<int> &slot_face = sah ? sahbvh.order : bvh.indices;
     std::vector<TriIsect> isect(n);
     std::vector<TriShade> shade(n);

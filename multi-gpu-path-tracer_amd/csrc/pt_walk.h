@@ -502,16 +502,19 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
 // order -- which is what the reference's in-order `t < ray_t.max` update computes over the
 // triangles it tests.  Differences from the reference are confined to rays for which the two
 // traversals test different triangles AND such a triangle wins.
+// Records of the SAH tree are addressed by 32-bit BYTE OFFSETS from the array bases (pt_upload_scene scales the
+// builder's links: pair index x 64, leaf-order slot x 48; both arrays stay far below 4 GB): a record's address is then
+// "uniform base + per-lane 32-bit offset", which a global load takes as it is, instead of a 64-bit multiply-add per step.
 struct SahWalk {
-    uint32_t pair;
+    uint32_t pair;                // byte offset of the NodePair to visit next
     int sp;
     float tbest;                  // t of the closest hit so far (the segment's t_max while there is none)
     uint32_t best_rank;
-    int best_slot;                // its leaf-order slot, -1 = none.  The barycentrics are not carried along the walk
-                                  // (two registers and two selects per triangle test): sah_hit() recomputes them for
-                                  // the winner, with the same arithmetic on the same operands -> the same bits
+    uint32_t best_off;            // byte offset of its TriIsect record, kNoPair = none.  The barycentrics are not carried
+                                  // along the walk (two registers and two selects per triangle test): sah_hit()
+                                  // recomputes them for the winner, same arithmetic, same operands -> the same bits
     v3 inv;
-    uint32_t k0, n0, k1, n1;      // pending leaf triangles: range 0 first, then range 1
+    uint32_t k0, n0, k1, n1;      // pending leaf triangles (byte offset, count): range 0 first, then range 1
     // `pair` == kNoPair: no node is left to visit.  (A register compare a vote can use directly: a bool carried across
     // trips is materialised as 0 / 1 and compared again for every ballot.)
 };
@@ -525,7 +528,7 @@ __device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
 {
     W.pair = 0; W.sp = 0; W.tbest = tmax0; W.best_rank = 0xFFFFFFFFu;
     W.inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
-    W.best_slot = -1;
+    W.best_off = 0xFFFFFFFFu;
     W.k0 = W.n0 = W.k1 = W.n1 = 0;
 }
 
@@ -538,18 +541,17 @@ __device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
 // the closest hit they may have produced.  Returns false when the walk is complete.
 __device__ __forceinline__ bool sah_tri_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin, uint32_t &n_tri)
 {
-    const float4 *tris = reinterpret_cast<const float4 *>(P.tris);
     {
-        const float4 *tp = tris + 3 * (size_t)W.k0;
+        const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.tris) + (size_t)W.k0);
         const float4 ta = tp[0], tb = tp[1], tc = tp[2];
         float t, u, v;
         n_tri++;
         const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d, t, u, v);
         const uint32_t rank = __float_as_uint(tc.y);
         if (ok & (t > tmin) & ((t < W.tbest) | ((t == W.tbest) & (rank < W.best_rank)))) {
-            W.tbest = t; W.best_rank = rank; W.best_slot = (int)W.k0;
+            W.tbest = t; W.best_rank = rank; W.best_off = W.k0;
         }
-        W.k0++; W.n0--;
+        W.k0 += (uint32_t)sizeof(TriIsect); W.n0--;
         if (W.n0 == 0) { W.k0 = W.k1; W.n0 = W.n1; W.n1 = 0; }
         return sah_walking(W);
     }
@@ -558,8 +560,7 @@ __device__ __forceinline__ bool sah_tri_step(const RenderParams &P, SahWalk &W, 
 __device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, uint32_t *stack, int stride,
                                               uint32_t &n_box)
 {
-    const float4 *nodes = reinterpret_cast<const float4 *>(P.nodes);
-    const float4 *np = nodes + 4 * (size_t)W.pair;
+    const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
     const float4 a = np[0], b = np[1], c = np[2], lf = np[3];
     const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
     const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
@@ -606,11 +607,12 @@ __device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W,
 // The finished walk's hit record.  want_uv: the scene has textures (the only reader of the barycentrics, pt_shade.h).
 __device__ __forceinline__ Hit sah_hit(const RenderParams &P, const SahWalk &W, v3 o, v3 d)
 {
-    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = W.best_slot;
-    if (W.best_slot >= 0) {
+    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+    if (W.best_off != 0xFFFFFFFFu) {
         h.t = W.tbest;
+        h.slot = (int)(W.best_off / (uint32_t)sizeof(TriIsect));        // once per segment (a multiply-high by a constant)
         if (P.any_tex) {
-            const float4 *tp = reinterpret_cast<const float4 *>(P.tris) + 3 * (size_t)W.best_slot;
+            const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.tris) + (size_t)W.best_off);
             const float4 ta = tp[0], tb = tp[1];
             const float e2z = reinterpret_cast<const float *>(tp + 2)[0];
             float t;
