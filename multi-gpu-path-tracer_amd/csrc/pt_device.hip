@@ -1168,7 +1168,9 @@ static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool 
 {
     if (walk == 3 && dev->sah_persistent) {
         const size_t scene_bytes = dev->n_pairs * sizeof(NodePair) + dev->n_tris * sizeof(TriIsect);
-        const bool six = dev->sah_waves == 6 || (dev->sah_waves == 0 && scene_bytes <= ((size_t)64 << 20));
+        (void)scene_bytes;      // round 1 picked the 6-wave build for cache-resident scenes; after round 2's diet the natural
+                                // (5-wave, spill-free) build is as fast there (C3 132.9 vs 133.8 ms) and faster on C4
+        const bool six = dev->sah_waves == 6;
         return six ? PT_KERNEL(dev::render_kernel_sah6) : PT_KERNEL(dev::render_kernel_sah);
     }
     if (walk == 3) return PT_KERNEL(dev::render_kernel<false, true, 3>);
