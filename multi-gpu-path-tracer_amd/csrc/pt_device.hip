@@ -306,18 +306,19 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
         const uint32_t total = (uint32_t)pt_popc(pt_ballot(W.n0 != 0) | pt_ballot(W.pair != kNoPair));
         if (total == 0) break;                            // wave-uniform: nobody has work left
         while (true) {
+            // who wants what: two register compares serve the vote AND the loop's exit test (lanes still walking)
+            const unsigned long long tri_mask = pt_ballot(W.n0 != 0), pair_mask = pt_ballot(W.pair != kNoPair);
+            const uint32_t still = (uint32_t)pt_popc(tri_mask | pair_mask);
+            if (still * 100u <= total * (uint32_t)P.spec_pct) break;      // (first pass: still == total, never true: spec_pct <= 99)
             // one kind of micro-step per trip, chosen by majority vote: the minority waits a trip
             // rather than making the whole wave run its block for a few lanes
-            const unsigned long long tri_mask = pt_ballot(W.n0 != 0), pair_mask = pt_ballot(W.pair != kNoPair);
             const int want_tri = pt_popc(tri_mask), want_node = pt_popc(pair_mask & ~tri_mask);
             if (want_tri >= want_node) {
                 if (sah_wants_tri(W)) (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
             } else {
                 if (sah_wants_node(W)) (void)sah_node_step(P, W, L.ro, L.rd, stack, kBlock, L.n_box);
             }
-            const uint32_t still = (uint32_t)pt_popc(pt_ballot(W.n0 != 0) | pt_ballot(W.pair != kNoPair));
             cost++;
-            if (still * 100u <= total * (uint32_t)P.spec_pct) break;
         }
         if (alive && !sah_walking(W)) shade(L, P, V, sah_hit(P, W, L.ro, L.rd));
     }
@@ -686,7 +687,7 @@ try {
     // diagnostic A/B switches for the sweeps under tools/ (DESIGN.md section 4b); none changes a byte of output,
     // out-of-range values are ignored
     if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;
-    if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 100) d->spec_pct = v; }
+    if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 99) d->spec_pct = v; }   // 100 would leave the walk loop before its first step
     if (const char *e = getenv("PTAMD_DEAL")) d->deal_auto = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_LRPT")) d->lrpt = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_SAH_WAVES")) { const int v = atoi(e); if (v == 5 || v == 6) d->sah_waves = v; }
