@@ -541,20 +541,34 @@ __device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
 // the closest hit they may have produced.  Returns false when the walk is complete.
 __device__ __forceinline__ bool sah_tri_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin, uint32_t &n_tri)
 {
+    // up to TWO pending triangles per step (leaves hold up to four, stored back to back): both records are requested
+    // before either is used, so the pair costs one memory round trip and one trip of the wave's loop instead of two
+    const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.tris) + (size_t)W.k0);
+    const bool two = W.n0 >= 2;
+    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+    float4 ua = ta, ub = tb, uc = tc;
+    if (two) { ua = tp[3]; ub = tp[4]; uc = tp[5]; }
     {
-        const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.tris) + (size_t)W.k0);
-        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
         float t, u, v;
-        n_tri++;
         const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d, t, u, v);
         const uint32_t rank = __float_as_uint(tc.y);
         if (ok & (t > tmin) & ((t < W.tbest) | ((t == W.tbest) & (rank < W.best_rank)))) {
             W.tbest = t; W.best_rank = rank; W.best_off = W.k0;
         }
-        W.k0 += (uint32_t)sizeof(TriIsect); W.n0--;
-        if (W.n0 == 0) { W.k0 = W.k1; W.n0 = W.n1; W.n1 = 0; }
-        return sah_walking(W);
     }
+    if (two) {
+        float t, u, v;
+        const bool ok = mt_eval(mk3(ua.x, ua.y, ua.z), mk3(ua.w, ub.x, ub.y), mk3(ub.z, ub.w, uc.x), o, d, t, u, v);
+        const uint32_t rank = __float_as_uint(uc.y);
+        if (ok & (t > tmin) & ((t < W.tbest) | ((t == W.tbest) & (rank < W.best_rank)))) {
+            W.tbest = t; W.best_rank = rank; W.best_off = W.k0 + (uint32_t)sizeof(TriIsect);
+        }
+    }
+    const uint32_t done = two ? 2u : 1u;
+    n_tri += done;
+    W.k0 += done * (uint32_t)sizeof(TriIsect); W.n0 -= done;
+    if (W.n0 == 0) { W.k0 = W.k1; W.n0 = W.n1; W.n1 = 0; }
+    return sah_walking(W);
 }
 
 __device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, uint32_t *stack, int stride,
