@@ -563,7 +563,7 @@ struct pt_device {
     int walk = 0;                 // traversal schedule: 0 per-lane, 1 uniform/mask, 2 uniform/stack, 3 SAH tree
     bool sah = false;             // uploaded with the opt-in SAH tree instead of the reference topology
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
-    int spec_pct = 50;            // ... and leaves the walk loop when <= this % of the walkers remain
+    int spec_pct = -1;            // ... and leaves the walk loop when <= this % of the walkers remain; -1 = by scene size (fill_params)
     int deal_cap = 768, deal_min = 48;   // dealt walk (kWalk 4): item list capacity per wave; in-place threshold (lanes)
     int sah_waves = 0;            // SAH kernel build: 0 = by scene size, 5 / 6 = force (PTAMD_SAH_WAVES, A/B runs)
     int lrpt = 0;                 // dealt kernel: issue priority by remaining samples (PTAMD_LRPT)
@@ -1101,7 +1101,14 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.n_tris = (int)dev->n_tris;
     P.queue_entries = dev->queue_entries;
     P.sah = dev->sah ? 1 : 0;
-    P.spec_pct = dev->spec_pct;
+    // How soon the SAH kernel's walk loop lets finished lanes shade and take their next segment.  Measured (tools/exp_pct.sh):
+    // a tree that lives in the caches wants few, well-filled shading passes (C3: 40 % -> 128.8 ms; 50: 131.2, 65: 138.7);
+    // a tree in HBM, whose every step waits on memory, wants its idle lanes refilled early (C4: 80 % -> 67.5 ms; 50: 72.2,
+    // 35: 77.3, 95: 81.4).
+    {
+        const size_t scene_bytes = dev->n_pairs * sizeof(NodePair) + dev->n_tris * sizeof(TriIsect);
+        P.spec_pct = dev->spec_pct >= 0 ? dev->spec_pct : (scene_bytes > ((size_t)64 << 20) ? 80 : 40);
+    }
     P.fold_bits = dev->fold_bits;
     P.deal_cap = 0; P.deal_min = dev->deal_min; P.any_tex = dev->any_tex ? 1 : 0; P.lrpt = dev->lrpt;
     P.tile_order = nullptr; P.tile_cost = nullptr; P.band_list = nullptr;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: A/B of the SAH kernel over an environment switch.  usage: VAR=<env name> VALS="a b c" bash tools/exp_c4.sh
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
-python3 -m pytest tests/test_gpu_sah.py tests/test_gpu_c4.py -m gpu -x -q 2>&1 | tail -2
+[ -n "$SKIP_TESTS" ] || python3 -m pytest tests/test_gpu_sah.py tests/test_gpu_c4.py -m gpu -x -q 2>&1 | tail -2
 : > gpurun_out/exp_c4.txt
 for v in ${VALS:-0}; do
   for cfg in "--config c4" "--config c3 --bvh sah"; do
