@@ -1080,7 +1080,7 @@ static size_t lds_bytes(const RenderParams &P, int block, bool stage)
     if (stage) f4 += (size_t)P.n_pairs * 4 + (size_t)P.n_tris * 3;
     f4 += ((size_t)P.stack_entries * block + 3) / 4;
     f4 += ((size_t)P.queue_entries * block * P.queue_dwords + 3) / 4;
-    if (P.shade_lds) f4 += (size_t)P.n_tris * 3 + (size_t)P.n_mats * 3 + (size_t)P.n_lights * 5;
+    if (P.shade_lds) f4 += (P.shade_lds == 1 ? (size_t)P.n_tris * 3 : 0) + (size_t)P.n_mats * 3 + (size_t)P.n_lights * 5;
     if (P.deal_cap > 0)       // dev::deal_carve
         f4 += (size_t)P.n_tris * 3 /* onb table, stage_shade_lds */ + (size_t)P.n_tris * 3 +
               (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 2 + 15) / 16);
@@ -1117,7 +1117,9 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.queue_dwords = (dev->packed_queue && !dev->legacy_on) ? 1 : 2;      // the extension kernel uses the unpacked queue
     P.n_mats = (int)dev->n_mats;
     // shading tables in LDS when they are small (Cornell box: 1.9 KB)
-    P.shade_lds = (dev->n_tris * 48 + dev->n_mats * 48 + (size_t)dev->n_lights * 80) <= 16 * 1024 ? 1 : 0;
+    // 1: TriShade, MatRec and LightRec tables all fit; 2: only the (small) material and light tables; 0: none
+    P.shade_lds = (dev->n_tris * 48 + dev->n_mats * 48 + (size_t)dev->n_lights * 80) <= 16 * 1024 ? 1
+                  : (dev->n_mats * 48 + (size_t)dev->n_lights * 80) <= 8 * 1024 ? 2 : 0;
     return PT_OK;
 }
 

@@ -46,7 +46,7 @@ struct RenderParams {
     int n_mats;                       // material records
     int spec_pct;                     // SAH kernel: leave the walk loop when <= this % of the walkers remain
     int sah;                          // 1: nodes/tris hold the opt-in SAH tree (traverse_sah)
-    int shade_lds;                    // 1: shade / material / light tables are staged in LDS
+    int shade_lds;                    // 1: shade / material / light tables are staged in LDS; 2: material and light tables only
     int deal_cap;                     // dealt walk (kWalk 4): per-wave item list capacity, 0 otherwise
     int deal_min;                     // ... a leaf hit by >= this many lanes of the wave is tested in place
     int lrpt;                         // dealt kernel: s_setprio by the share of samples still to trace

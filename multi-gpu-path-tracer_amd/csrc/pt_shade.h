@@ -164,23 +164,26 @@ __device__ __forceinline__ ShadeViewLds stage_shade_lds(const RenderParams &P, f
 
 __device__ __forceinline__ ShadeView stage_shade(const RenderParams &P, float4 *lds, int tid, int block)
 {
+    // shade_lds = 1: all three tables in LDS; 2: only the material and light tables (a scene of millions of triangles
+    // still has a handful of materials and lights: the hit's TriShade record comes from memory, the two lookups that
+    // depend on it do not pay a second and third round trip).
     ShadeView V;
+    const float4 *gs = reinterpret_cast<const float4 *>(P.shade);
+    const float4 *gm = reinterpret_cast<const float4 *>(P.mats);
+    const float4 *gl = reinterpret_cast<const float4 *>(P.lights);
     if (P.shade_lds) {
-        const float4 *gs = reinterpret_cast<const float4 *>(P.shade);
-        const float4 *gm = reinterpret_cast<const float4 *>(P.mats);
-        const float4 *gl = reinterpret_cast<const float4 *>(P.lights);
-        const int ns = P.n_tris * 3, nm = P.n_mats * 3, nl = P.n_lights * 5;
+        const int ns = P.shade_lds == 1 ? P.n_tris * 3 : 0, nm = P.n_mats * 3, nl = P.n_lights * 5;
         for (int i = tid; i < ns; i += block) lds[i] = gs[i];
         for (int i = tid; i < nm; i += block) lds[ns + i] = gm[i];
         for (int i = tid; i < nl; i += block) lds[ns + nm + i] = gl[i];
         __syncthreads();
-        V.shade = lds; V.mats = lds + ns; V.lights = lds + ns + nm;
+        V.shade = ns ? lds : gs; V.mats = lds + ns; V.lights = lds + ns + nm;
         V.end = lds + ns + nm + nl;
     } else {
         V.end = lds;
-        V.shade = reinterpret_cast<const float4 *>(P.shade);
-        V.mats = reinterpret_cast<const float4 *>(P.mats);
-        V.lights = reinterpret_cast<const float4 *>(P.lights);
+        V.shade = gs;
+        V.mats = gm;
+        V.lights = gl;
     }
     return V;
 }
