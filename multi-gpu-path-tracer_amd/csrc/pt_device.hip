@@ -128,65 +128,74 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
     extern __shared__ float4 lds_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-#ifdef PT_TIMELINE
-    const uint32_t tl_start = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
-    int x, y, pixel_index;
-    const bool in_frame = lane_pixel(P, tid, x, y, pixel_index);
     const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
     const ShadeViewLds V = stage_shade_lds(P, LL.tail, tid, kBlock);      // the host picks this kernel only when the tables fit
     const DealView D = deal_carve(P, V.end, tid, kBlock);
-    PathState L;
-    path_init(L, P, pixel_index);
-    bool alive = in_frame && P.depth > 0;
-    // wave totals in scalar registers: box / triangle tests (as in the mask walk), segments (lanes that trace in a trip)
-    // and the trip count itself, which is this tile's cost for the next launch's order
-    unsigned long long wave_box = 0, wave_tri = 0;
-    uint32_t wave_seg = 0, trips = 0;
-    // Issue priority by remaining work (P.lrpt; measured neutral): a wave that still has most of its samples
-    // ahead outranks one that is nearly done.
-    int prio_now = 0;
+    // Persistent waves: the launch has as many workgroups as the device holds at once, and every WAVE takes its next tile
+    // from a counter when its own tile is done.  With one workgroup per four tiles a finished wave's slot stayed empty until
+    // its three siblings were done too (5 % of the slots of a C2 frame), and the shading tables were staged 8 100 times.
     while (true) {
-        const unsigned long long alive_mask = pt_ballot(alive);
-        if (alive_mask == 0ull) break;
-        if (P.lrpt) {
-            const int s_now = __builtin_amdgcn_readlane(L.s, (int)__builtin_ctzll(alive_mask));     // a tile's pixels progress within a few %
-            const int left4 = (P.spp - s_now) * 4;
-            const int want = left4 > 3 * P.spp ? 3 : left4 > 2 * P.spp ? 2 : left4 > P.spp ? 1 : 0;
-            if (want != prio_now) {
-                prio_now = want;
-                if (want == 3) __builtin_amdgcn_s_setprio(3);
-                else if (want == 2) __builtin_amdgcn_s_setprio(2);
-                else if (want == 1) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
-            }
-        }
-        bool trace = alive;
-        if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
-        const unsigned long long trace_mask = pt_ballot(trace);
-        if (trace_mask != 0ull) {                          // (the last trip of a wave only discovers that every pixel is done)
-            wave_seg += (uint32_t)__popcll(trace_mask);
-            trips++;
-        }
-        const Hit h = traverse_uniform_dealt<kInPlace>(P, D, lane, trace, L.ro, L.rd, 0.001f, 3.402823466e+38f, wave_box, wave_tri);
-        if (trace) shade<false, ShadeViewLds>(L, P, V, h);
-    }
-    if (in_frame) write_pixel(P, L.col, pixel_index);
-    L.n_paths = in_frame ? (P.depth == 0 ? (uint32_t)P.spp : (uint32_t)L.s) : 0u;      // samples started (depth 0: rays generated, untraced)
-    L.n_seg = 0;
-    flush_counters(P, L, lane, wave_box, wave_tri, wave_seg);
-    record_tile_cost(P, tid, trips);
+        KernargParams &K = *fresh_kernarg();
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(K.tile_next, 1u);
+        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+        if (slot >= K.n_slots) break;                      // every wave gets here: the counter only grows
 #ifdef PT_TIMELINE
-    {
-        const uint32_t slot = blockIdx.x * kWavesPerBlock + tid / kWave;
+        const uint32_t tl_start = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
+        const int tile = K.tile_order ? (int)K.tile_order[slot] : (int)slot;
+        int x, y, pixel_index;
+        const bool in_frame = tile_pixel(K, tile, lane, x, y, pixel_index);
+        PathState L;
+        path_init(L, P, pixel_index);
+        bool alive = in_frame && P.depth > 0;
+        // wave totals in scalar registers: box / triangle tests (as in the mask walk), segments (lanes that trace in a trip)
+        // and the trip count itself, which is this tile's cost for the next launch's order
+        unsigned long long wave_box = 0, wave_tri = 0;
+        uint32_t wave_seg = 0, trips = 0;
+        // Issue priority by remaining work (P.lrpt; measured neutral): a wave that still has most of its samples
+        // ahead outranks one that is nearly done.
+        int prio_now = 0;
+        while (true) {
+            const unsigned long long alive_mask = pt_ballot(alive);
+            if (alive_mask == 0ull) break;
+            if (P.lrpt) {
+                const int s_now = __builtin_amdgcn_readlane(L.s, (int)__builtin_ctzll(alive_mask));     // a tile's pixels progress within a few %
+                const int left4 = (P.spp - s_now) * 4;
+                const int want = left4 > 3 * P.spp ? 3 : left4 > 2 * P.spp ? 2 : left4 > P.spp ? 1 : 0;
+                if (want != prio_now) {
+                    prio_now = want;
+                    if (want == 3) __builtin_amdgcn_s_setprio(3);
+                    else if (want == 2) __builtin_amdgcn_s_setprio(2);
+                    else if (want == 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+            }
+            bool trace = alive;
+            if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
+            const unsigned long long trace_mask = pt_ballot(trace);
+            if (trace_mask != 0ull) {                          // (the last trip of a wave only discovers that every pixel is done)
+                wave_seg += (uint32_t)__popcll(trace_mask);
+                trips++;
+            }
+            const Hit h = traverse_uniform_dealt<kInPlace>(P, D, lane, trace, L.ro, L.rd, 0.001f, 3.402823466e+38f, wave_box, wave_tri);
+            if (trace) shade<false, ShadeViewLds>(L, P, V, h);
+        }
+        KernargParams &E = *fresh_kernarg();
+        if (in_frame) write_pixel(E, L.col, pixel_index);
+        L.n_paths = in_frame ? (P.depth == 0 ? (uint32_t)P.spp : (uint32_t)L.s) : 0u;      // samples started (depth 0: rays generated, untraced)
+        L.n_seg = 0;
+        flush_counters(E, L, lane, wave_box, wave_tri, wave_seg);
+        if (E.tile_cost && lane == 0) E.tile_cost[tile] = trips;
+#ifdef PT_TIMELINE
         if (lane == 0 && slot < 131072u) {
             g_timeline[4 * slot] = tl_start;
             g_timeline[4 * slot + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-            g_timeline[4 * slot + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));                       // HW_ID
-            g_timeline[4 * slot + 3] = (trips & 0xffffu) | (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16);   // cost | XCC_ID << 16
+            g_timeline[4 * slot + 2] = (uint32_t)tile;
+            g_timeline[4 * slot + 3] = trips;
         }
-    }
 #endif
+    }
 }
 
 // Cooperative kernel for reference trees with big leaves (cornell_duck: one leaf of 1603 triangles, 2 120
@@ -272,66 +281,85 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
     extern __shared__ float4 lds_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    int x, y;
-    bool in_frame;
-    { int pixel_index; in_frame = lane_pixel(P, tid, x, y, pixel_index); }      // the pixel index is recomputed for the final store
     const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
     const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
     uint32_t *stack = LL.stack + tid;
-
-    PathState L;
-    { int x0, y0, pixel_index; (void)lane_pixel(P, tid, x0, y0, pixel_index); path_init(L, P, pixel_index); }
-    SahWalk W;
-    sah_begin(W, mk3(1.0f, 1.0f, 1.0f), 0.0f);
-    W.pair = kNoPair;                                      // nobody walks yet
-    bool alive = in_frame && P.depth > 0;
-    uint32_t cost = 0;                                    // wave-uniform: micro-step trips + 8 per outer trip
-    // Box / triangle tests are counted per lane (one masked add per micro-step; a wave-level sum of the vote's popcounts
-    // was tried: the compiler keeps such a loop-carried uniform sum in vector registers and spends four instructions per
-    // trip on its carry) and folded into wider per-lane words once per outer trip, long before 32 bits can wrap.
-    uint32_t wave_seg = 0;
+    // persistent waves, as in render_kernel_dealt: every wave takes its next tile from the launch's counter
     while (true) {
-        cost += 8;
-        fold_counters(L, P.fold_bits);
-        bool begins = false;
-        if (alive && !sah_walking(W)) {
-            if (L.need_new && !start_path(L, P, x, y)) {
-                alive = false;
-            } else {
-                begins = true;
-                sah_begin(W, L.rd, 3.402823466e+38f);
-            }
-        }
-        wave_seg += (uint32_t)__builtin_popcountll(pt_ballot(begins));
-        const uint32_t total = (uint32_t)pt_popc(pt_ballot(W.n0 != 0) | pt_ballot(W.pair != kNoPair));
-        if (total == 0) break;                            // wave-uniform: nobody has work left
+        KernargParams &K = *fresh_kernarg();
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(K.tile_next, 1u);
+        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+        if (slot >= K.n_slots) break;                      // every wave gets here: the counter only grows
+#ifdef PT_TIMELINE
+        const uint32_t tl_start = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
+        const int tile = K.tile_order ? (int)K.tile_order[slot] : (int)slot;
+        int x, y;
+        bool in_frame;
+        PathState L;
+        { int pixel_index; in_frame = tile_pixel(K, tile, lane, x, y, pixel_index); path_init(L, P, pixel_index); }      // the pixel index is recomputed for the final store
+        SahWalk W;
+        sah_begin(W, mk3(1.0f, 1.0f, 1.0f), 0.0f);
+        W.pair = kNoPair;                                      // nobody walks yet
+        bool alive = in_frame && P.depth > 0;
+        uint32_t cost = 0;                                    // wave-uniform: micro-step trips + 8 per outer trip
+        // Box / triangle tests are counted per lane (one masked add per micro-step; a wave-level sum of the vote's popcounts
+        // was tried: the compiler keeps such a loop-carried uniform sum in vector registers and spends four instructions per
+        // trip on its carry) and folded into wider per-lane words once per outer trip, long before 32 bits can wrap.
+        uint32_t wave_seg = 0;
         while (true) {
-            // who wants what: two register compares serve the vote AND the loop's exit test (lanes still walking)
-            const unsigned long long tri_mask = pt_ballot(W.n0 != 0), pair_mask = pt_ballot(W.pair != kNoPair);
-            const uint32_t still = (uint32_t)pt_popc(tri_mask | pair_mask);
-            if (still * 100u <= total * (uint32_t)P.spec_pct) break;      // (first pass: still == total, never true: spec_pct <= 99)
-            // one kind of micro-step per trip, chosen by majority vote: the minority waits a trip
-            // rather than making the whole wave run its block for a few lanes
-            const int want_tri = pt_popc(tri_mask), want_node = pt_popc(pair_mask & ~tri_mask);
-            if (want_tri >= want_node) {
-                if (sah_wants_tri(W)) (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
-            } else {
-                if (sah_wants_node(W)) (void)sah_node_step(P, W, L.ro, L.rd, stack, kBlock, L.n_box);
+            cost += 8;
+            fold_counters(L, P.fold_bits);
+            bool begins = false;
+            if (alive && !sah_walking(W)) {
+                if (L.need_new && !start_path(L, P, x, y)) {
+                    alive = false;
+                } else {
+                    begins = true;
+                    sah_begin(W, L.rd, 3.402823466e+38f);
+                }
             }
-            cost++;
+            wave_seg += (uint32_t)__builtin_popcountll(pt_ballot(begins));
+            const uint32_t total = (uint32_t)pt_popc(pt_ballot(W.n0 != 0) | pt_ballot(W.pair != kNoPair));
+            if (total == 0) break;                            // wave-uniform: nobody has work left
+            while (true) {
+                // who wants what: two register compares serve the vote AND the loop's exit test (lanes still walking)
+                const unsigned long long tri_mask = pt_ballot(W.n0 != 0), pair_mask = pt_ballot(W.pair != kNoPair);
+                const uint32_t still = (uint32_t)pt_popc(tri_mask | pair_mask);
+                if (still * 100u <= total * (uint32_t)P.spec_pct) break;      // (first pass: still == total, never true: spec_pct <= 99)
+                // one kind of micro-step per trip, chosen by majority vote: the minority waits a trip
+                // rather than making the whole wave run its block for a few lanes
+                const int want_tri = pt_popc(tri_mask), want_node = pt_popc(pair_mask & ~tri_mask);
+                if (want_tri >= want_node) {
+                    if (sah_wants_tri(W)) (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
+                } else {
+                    if (sah_wants_node(W)) (void)sah_node_step(P, W, L.ro, L.rd, stack, kBlock, L.n_box);
+                }
+                cost++;
+            }
+            if (alive && !sah_walking(W)) shade(L, P, V, sah_hit(P, W, L.ro, L.rd));
         }
-        if (alive && !sah_walking(W)) shade(L, P, V, sah_hit(P, W, L.ro, L.rd));
+        KernargParams &E = *fresh_kernarg();
+        {
+            int x0, y0, pixel_index;
+            (void)tile_pixel(E, tile, lane, x0, y0, pixel_index);
+            if (in_frame) write_pixel(E, L.col, pixel_index);
+        }
+        // paths = samples started (all of them when depth == 0: camera rays are generated, then ray_color returns untraced)
+        L.n_paths = in_frame ? (P.depth == 0 ? (uint32_t)P.spp : (uint32_t)L.s) : 0u;
+        L.n_seg = 0;
+        flush_counters(E, L, lane, 0ull, 0ull, wave_seg);
+        if (E.tile_cost && lane == 0) E.tile_cost[tile] = cost;
+#ifdef PT_TIMELINE
+        if (lane == 0 && slot < 131072u) {
+            g_timeline[4 * slot] = tl_start;
+            g_timeline[4 * slot + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            g_timeline[4 * slot + 2] = (uint32_t)tile;
+            g_timeline[4 * slot + 3] = cost;
+        }
+#endif
     }
-    {
-        int x0, y0, pixel_index;
-        (void)lane_pixel(P, tid, x0, y0, pixel_index);
-        if (in_frame) write_pixel(P, L.col, pixel_index);
-    }
-    // paths = samples started (all of them when depth == 0: camera rays are generated, then ray_color returns untraced)
-    L.n_paths = in_frame ? (P.depth == 0 ? (uint32_t)P.spp : (uint32_t)L.s) : 0u;
-    L.n_seg = 0;
-    flush_counters(P, L, lane, 0ull, 0ull, wave_seg);
-    record_tile_cost(P, tid, cost);
 }
 
 // Two builds of the same body.  Its natural allocation is 93 VGPRs (5 waves/SIMD).  Scenes whose tree
@@ -566,7 +594,7 @@ struct pt_device {
     int spec_pct = -1;            // ... and leaves the walk loop when <= this % of the walkers remain; -1 = by scene size (fill_params)
     int deal_cap = 768, deal_min = 48;   // dealt walk (kWalk 4): item list capacity per wave; in-place threshold (lanes)
     int sah_waves = 0;            // SAH kernel build: 0 = by scene size, 5 / 6 = force (PTAMD_SAH_WAVES, A/B runs)
-    int lrpt = 0;                 // dealt kernel: issue priority by remaining samples (PTAMD_LRPT)
+    int lrpt = 1;                 // dealt kernel: issue priority by remaining samples (PTAMD_LRPT=0: off)
     bool deal_auto = true;        // automatic choice prefers the dealt walk over the plain mask walk (PTAMD_DEAL=0: off)
     bool any_tex = false;
     int fold_bits = 31;           // per-lane test counters fold at 2^fold_bits (PTAMD_FOLD_BITS lowers it: tests of the folding)
@@ -593,7 +621,17 @@ struct pt_device {
     uint64_t schedule_clock = 0;
     // kernel timing
     std::mutex mu;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, free_events;
+    // per launch: the two timing events and, for the persistent kernels, the counter its waves take their tiles from.
+    // The triple is reused only after the launch's second event has completed, so launches in flight on different
+    // streams never share a counter.
+    struct LaunchEvents { hipEvent_t first = nullptr, second = nullptr; uint32_t *next = nullptr; };
+    std::vector<LaunchEvents> pending, free_events;
+    std::vector<uint32_t *> next_chunks;      // tile counters, 256 per allocation, one 64-byte line each
+    size_t next_used = 0;
+    int cu_count = 256;
+    int resident_cap = 0;         // persistent kernels: at most this many workgroups per CU (PTAMD_RESIDENT; 0 = what fits)
+    struct Resident { const void *kern; size_t lds; int blocks; };
+    std::vector<Resident> resident_blocks;      // per kernel and LDS size: workgroups one CU holds (persistent grids)
     double ms_total = 0.0;
     uint64_t launches = 0;
     const char *last_kernel = "";  // what the latest render launch ran (pt_kernel_name_read)
@@ -693,12 +731,14 @@ try {
     if (const char *e = getenv("PTAMD_SAH_WAVES")) { const int v = atoi(e); if (v == 5 || v == 6) d->sah_waves = v; }
     if (const char *e = getenv("PTAMD_DEAL_MIN")) { const int v = atoi(e); if (v >= 0 && v <= 65) d->deal_min = v; }
     if (const char *e = getenv("PTAMD_DEAL_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 8192) d->deal_cap = v & ~7; }
+    if (const char *e = getenv("PTAMD_RESIDENT")) { const int v = atoi(e); if (v >= 1 && v <= 16) d->resident_cap = v; }
     if (const char *e = getenv("PTAMD_FOLD_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 31) d->fold_bits = v; }
     if (const char *e = getenv("PTAMD_COOP")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->coop_mode = v; }
     {
         hipDeviceProp_t prop;
         PT_HIP(hipGetDeviceProperties(&prop, device_index));
         d->max_waves = std::max(1, prop.multiProcessorCount) * 4 * 8;
+        d->cu_count = std::max(1, prop.multiProcessorCount);
         d->lds_limit = std::max<size_t>((size_t)64 * 1024, std::max((size_t)prop.sharedMemPerBlock, (size_t)prop.maxSharedMemoryPerMultiProcessor));
     }
     PT_HIP(hipMalloc((void **)&d->d_counters, 8 * sizeof(unsigned long long)));
@@ -718,6 +758,7 @@ try {
     (void)hipFree(dev->d_counters);
     for (auto &pr : dev->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto &pr : dev->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (uint32_t *c : dev->next_chunks) (void)hipFree(c);
     delete dev;
     return PT_OK;
 } PT_CATCH_ALL
@@ -1211,6 +1252,17 @@ static pt_status ensure_lds(pt_device *dev, const void *kern, size_t lds)
     return PT_OK;
 }
 
+// Workgroups of `kern` one CU holds at once with `lds` bytes of dynamic LDS (the grid of a persistent launch).
+static int resident_per_cu(pt_device *dev, const void *kern, size_t lds)
+{
+    std::lock_guard<std::mutex> lk(dev->mu);
+    for (auto &r : dev->resident_blocks) if (r.kern == kern && r.lds == lds) return r.blocks;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, dev::kBlock, lds) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 8; }
+    dev->resident_blocks.push_back({kern, lds, n});
+    return n;
+}
+
 static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream)
 {
     long long tiles = (long long)P.tiles_x * P.tiles_y;
@@ -1235,8 +1287,9 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         const pt_status st = ensure_lds(dev, (const void *)kern, lds);
         if (st != PT_OK) return st;
     }
+    const bool persistent = walk == 4 || (walk == 3 && dev->sah_persistent);
     hipStream_t hs = (hipStream_t)stream;
-    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    pt_device::LaunchEvents ev;
     TileSchedule *sched = nullptr;
     P.tile_order = nullptr; P.tile_cost = nullptr;
     // An error between here and the bookkeeping at the end gives the event pair back and releases the schedule.
@@ -1260,10 +1313,18 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         if (!dev->free_events.empty()) { ev = dev->free_events.back(); dev->free_events.pop_back(); }
         else {
             hipError_t e1 = hipEventCreate(&ev.first), e2 = e1 == hipSuccess ? hipEventCreate(&ev.second) : e1;
+            if (e2 == hipSuccess && dev->next_used % 256 == 0) {
+                uint32_t *chunk = nullptr;
+                e2 = hipMalloc((void **)&chunk, 256 * 64);
+                if (e2 == hipSuccess) dev->next_chunks.push_back(chunk);
+            }
             if (e2 != hipSuccess) {
                 if (ev.first) (void)hipEventDestroy(ev.first);
+                if (ev.second) (void)hipEventDestroy(ev.second);
                 return set_error(PT_ERR_HIP, std::string("HIP ERROR = ") + std::to_string((int)e2) + " (" + hipGetErrorString(e2) + ") creating a timing event");
             }
+            ev.next = dev->next_chunks.back() + (dev->next_used % 256) * 16;
+            dev->next_used++;
         }
         // one wave slot per tile; tiny launches are not worth a sort
         if (dev->tile_schedule == 1 && blocks >= 64) sched = schedule_for(dev, P, coop ? blocks : blocks * dev::kWavesPerBlock, hs);
@@ -1285,6 +1346,14 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         }
     }
     PT_HIP_LAUNCH(hipEventRecord(ev.first, hs));
+    if (persistent) {
+        // as many workgroups as the device holds at once; their waves take tiles from ev.next until it passes n_slots
+        P.tile_next = ev.next; P.n_slots = blocks * dev::kWavesPerBlock;
+        PT_HIP_LAUNCH(hipMemsetAsync(P.tile_next, 0, sizeof(uint32_t), hs));
+        int per_cu = resident_per_cu(dev, (const void *)kern, lds);
+        if (dev->resident_cap > 0) per_cu = std::min(per_cu, dev->resident_cap);
+        blocks = std::min(blocks, (unsigned)(dev->cu_count * per_cu));
+    }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     PT_HIP_LAUNCH(hipGetLastError());
     PT_HIP_LAUNCH(hipEventRecord(ev.second, hs));

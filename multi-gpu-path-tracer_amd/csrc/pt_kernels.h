@@ -28,6 +28,8 @@ struct RenderParams {
     unsigned long long *counters;     // 5 x u64: paths, segments, box, tri, light
     const uint32_t *tile_order;       // adaptive schedule: wave slot -> tile (a permutation), or null = raster order
     uint32_t *tile_cost;              // adaptive schedule: shader-clock cost of each tile, written per wave, or null
+    uint32_t *tile_next;              // persistent launches: the next slot to hand out (zeroed before the launch), or null
+    uint32_t n_slots;                 // persistent launches: slots (tiles) of this launch
     CameraBasis cam;
     double light_index_scale;         // (n-1) + 0.999999, hitable_list.h:24
     float light_weight;               // 1.0f / n, hitable_list.h:17

@@ -504,7 +504,8 @@ __device__ __forceinline__ void shade(PathState &L, const RenderParams &P, const
 }
 
 // Quantisation + RGB / YUV420 store of one pixel, DevicePathTracer.h:98-119.
-__device__ __forceinline__ void write_pixel(const RenderParams &P, v3 col, int pixel_index)
+template <class Params>
+__device__ __forceinline__ void write_pixel(Params &P, v3 col, int pixel_index)
 {
 {
     // :98-119
@@ -528,7 +529,8 @@ __device__ __forceinline__ void write_pixel(const RenderParams &P, v3 col, int p
 // Exact work counters: one atomic per wave per counter.
 // wave_box / wave_tri: totals a wave-uniform walk (traverse_uniform, traverse_uniform_stack) kept for the whole
 // wave.  A lane stops adding to its copy when its pixel is done, so the lane that ran longest holds the total.
-__device__ __forceinline__ void flush_counters(const RenderParams &P, const PathState &L, int lane,
+template <class Params>
+__device__ __forceinline__ void flush_counters(Params &P, const PathState &L, int lane,
                                                unsigned long long wave_box = 0, unsigned long long wave_tri = 0, uint32_t wave_seg = 0)
 {
     const uint32_t c0 = wave_sum(L.n_paths), c1 = wave_sum(L.n_seg) + wave_seg, c4 = wave_sum(L.n_light);
@@ -542,6 +544,18 @@ __device__ __forceinline__ void flush_counters(const RenderParams &P, const Path
         atomicAdd(&P.counters[3], c3);
         atomicAdd(&P.counters[4], (unsigned long long)c4);
     }
+}
+
+// The launch parameters as they lie in the kernel-argument segment (constant address space: scalar loads).  The persistent
+// kernels read what only a tile's prologue or epilogue needs through a pointer the compiler must take as new each time
+// (the empty asm), so those fields are loaded where they are used instead of sitting in SGPRs through every trip of the
+// tile's loop -- held live across the tile loop they push that loop's own scalars into spills.
+typedef const __attribute__((address_space(4))) RenderParams KernargParams;
+__device__ __forceinline__ KernargParams *fresh_kernarg()
+{
+    KernargParams *k = (KernargParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
 }
 
 // Tile of this wave: its launch slot, or what the adaptive schedule assigns to that slot.
@@ -569,14 +583,16 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 // (j % band_rows) of this rank's (j / band_rows)-th band, band b of the frame (fb rows, 0 = top)
 // belonging to rank b % band_ranks; with an explicit band list (pt_render_band_list_async) it is row (j % band_rows)
 // of band band_list[j / band_rows].
-__device__ __forceinline__ bool tile_pixel(const RenderParams &P, int tile, int lane, int &x, int &y, int &pixel_index);
+template <class Params>
+__device__ __forceinline__ bool tile_pixel(Params &P, int tile, int lane, int &x, int &y, int &pixel_index);
 
 __device__ __forceinline__ bool lane_pixel(const RenderParams &P, int tid, int &x, int &y, int &pixel_index)
 {
     return tile_pixel(P, wave_tile(P, tid), tid & (kWave - 1), x, y, pixel_index);
 }
 
-__device__ __forceinline__ bool tile_pixel(const RenderParams &P, int tile, int lane, int &x, int &y, int &pixel_index)
+template <class Params>
+__device__ __forceinline__ bool tile_pixel(Params &P, int tile, int lane, int &x, int &y, int &pixel_index)
 {
     const int tile_x = tile % P.tiles_x, tile_y = tile / P.tiles_x;
     const int i = tile_x * 8 + (lane & 7), j = tile_y * 8 + (lane >> 3);
