@@ -64,6 +64,32 @@ def test_band_tasks_on_several_streams_equal_whole_frame(pt, duck_scene, duck_or
     tr.close()
 
 
+@pytest.mark.parametrize("bvh,kernel", [(0, "dealt"), (1, "sah")])
+def test_persistent_kernels_with_many_launches_in_flight(pt, box_scene, box_oracle, gpu_device, bvh, kernel):
+    """The dealt and SAH kernels are persistent: a launch's waves take their tiles from a counter of that launch.  Many
+    small launches queued on three streams without waiting (more than the 64 the event pool folds at, so counters
+    are recycled while others are in flight) must still paint exactly the oracle's frame, and a second pass over the
+    recycled counters must change nothing."""
+    import torch
+    W, H, spp, depth = 96, 72, 3, 4
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]), bvhMode=bvh)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    tasks = [pt.RenderTask(24, 8, ox, oy) for oy in range(0, H, 8) for ox in range(0, W, 24)] + \
+            [pt.RenderTask(W, 8, 0, oy) for oy in range(0, H, 8)] + [pt.RenderTask(W, H, 0, 0)]
+    ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    for sweep in range(3):
+        for i, t in enumerate(tasks):
+            tr.renderTaskAsync(t, streams[i % 3])
+        for s in streams:
+            tr.synchronizeStream(s)
+        assert kernel in tr.kernelName()
+        assert np.array_equal(fb.rgb_host(), ref[0]) and np.array_equal(fb.yuv_host(), ref[1]), "sweep %d" % sweep
+    ms, n = tr.kernelTime()
+    assert n == 3 * len(tasks)
+    tr.close()
+
+
 @pytest.mark.parametrize("W,H,band,world", [(64, 36, 8, 3), (100, 50, 4, 4), (64, 64, 16, 2)])
 def test_single_launch_bands_equal_whole_frame(pt, box_scene, box_oracle, gpu_device, W, H, band, world):
     """pt_render_bands_async: one launch per rank covering all its bands (incl. a partial last

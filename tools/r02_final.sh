@@ -9,5 +9,6 @@ bash tools/profile_c2.sh ${T}_c2 --config c2 --no-host-visible; echo "profile c2
 cd $R && bash tools/profile_c2.sh ${T}_c4 --config c4 --no-host-visible; echo "profile c4 done"
 cd $R && bash tools/profile_c2.sh ${T}_c3sah --config c3 --bvh sah --no-host-visible; echo "profile c3 sah done"
 cd $R && bash tools/shares_json.sh gpurun_out/${T}_shares.jsonl
-cd $R && bash tools/timeline.sh ${T} 1080
+cd $R && bash tools/timeline.sh ${T} c2
+cd $R && bash tools/lone_tile.sh c4 3 > gpurun_out/${T}_c4_lone_tiles.txt 2>&1; bash tools/timeline.sh ${T}_c4 c4
 cd $R && python3 bench.py > gpurun_out/${T}_bench.log 2>&1; tail -1 gpurun_out/${T}_bench.log
