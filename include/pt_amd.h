@@ -189,6 +189,10 @@ PT_API pt_status pt_counters_reset(pt_device *dev);
  * PT_STAMPS build (tools/stamps.sh): longest wave lifetime, summed traversal cycles, summed
  * wave lifetimes, in shader-clock cycles.                                                */
 PT_API pt_status pt_debug_counters_read(pt_device *dev, uint64_t out8[8]);
+/* How many of its dearest tiles the NEXT launch of the latest launch's rectangle hands to several waves each (SAH
+ * kernel; 0 when the cost-ordered tile schedule is off, the launch was tiny or the walk is another).
+ * Waits for the stream of that launch.                                                    */
+PT_API pt_status pt_split_tiles_read(pt_device *dev, uint32_t *n_split);
 /* Accumulated device time (ms) of the render kernel launches since the last reset,
  * measured with HIP events on the launch stream; n_launches may be NULL.                */
 PT_API pt_status pt_kernel_time_read(pt_device *dev, double *ms_total, uint64_t *n_launches);

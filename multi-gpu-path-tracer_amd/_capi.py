@@ -89,6 +89,7 @@ _PROTOS = {
     "pt_counters_read": (C.c_int, [_vp, C.POINTER(Counters)]),
     "pt_counters_reset": (C.c_int, [_vp]),
     "pt_debug_counters_read": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "pt_split_tiles_read": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "pt_kernel_time_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "pt_kernel_time_reset": (C.c_int, [_vp]),
     "pt_kernel_name_read": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),

@@ -284,21 +284,46 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
     const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
     const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
     uint32_t *stack = LL.stack + tid;
-    // persistent waves, as in render_kernel_dealt: every wave takes its next tile from the launch's counter
+    // Persistent waves, as in render_kernel_dealt: every wave takes its next tile from the launch's counter.
+    // Split tiles.  A pixel's samples are one chain, and on a scene like C4's terrain the few dearest tiles (rays skimming
+    // the ground towards the horizon) cost five times the median: started first, they still end last, alone on the
+    // device, and the frame is as long as their chain, not as the device's work.  Such a tile's pixels diverge (each
+    // trip of the wave serves one kind of micro-step), so fewer pixels per wave shorten the chain: measured alone,
+    // 39 ms as 8 x 8, 30-35 ms as 4 x 1, 22 ms for a single pixel (tools/lone_tile.sh).  The first n_split tiles of the
+    // order (split_count_kernel) are therefore handed out as `parts` slots of 64 / parts pixels each; the other lanes of
+    // those waves idle, which costs a per cent of the slots.  Which wave renders a pixel never changes its value.
+    const uint32_t parts = (uint32_t)P.split_parts;
+    uint32_t n_split = 0, n_slots_all = 0;
+    {
+        KernargParams &K = *fresh_kernarg();
+        if (K.n_split) n_split = K.n_split[0];
+        n_slots_all = K.n_slots + n_split * (parts - 1u);
+    }
     while (true) {
         KernargParams &K = *fresh_kernarg();
         uint32_t slot = 0;
         if (lane == 0) slot = atomicAdd(K.tile_next, 1u);
         slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-        if (slot >= K.n_slots) break;                      // every wave gets here: the counter only grows
+        if (slot >= n_slots_all) break;                    // every wave gets here: the counter only grows
 #ifdef PT_TIMELINE
         const uint32_t tl_start = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
-        const int tile = K.tile_order ? (int)K.tile_order[slot] : (int)slot;
+        const bool is_part = slot < n_split * parts;
+        const uint32_t entry = is_part ? slot / parts : slot - n_split * (parts - 1u);
+        const int tile = K.tile_order ? (int)K.tile_order[entry] : (int)entry;
+        // lane -> pixel of the 8 x 8 tile: all 64, or the 64 / parts consecutive ones of part (slot % parts)
+        int tile_lane = lane;
+        bool lane_on = true;
+        if (is_part) {
+            const uint32_t per = 64u / parts;
+            tile_lane = (int)((slot % parts) * per + (uint32_t)lane);
+            lane_on = (uint32_t)lane < per;
+            if (!lane_on) tile_lane = 0;
+        }
         int x, y;
         bool in_frame;
         PathState L;
-        { int pixel_index; in_frame = tile_pixel(K, tile, lane, x, y, pixel_index); path_init(L, P, pixel_index); }      // the pixel index is recomputed for the final store
+        { int pixel_index; in_frame = tile_pixel(K, tile, tile_lane, x, y, pixel_index) && lane_on; path_init(L, P, pixel_index); }      // the pixel index is recomputed for the final store
         SahWalk W;
         sah_begin(W, mk3(1.0f, 1.0f, 1.0f), 0.0f);
         W.pair = kNoPair;                                      // nobody walks yet
@@ -343,19 +368,24 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
         KernargParams &E = *fresh_kernarg();
         {
             int x0, y0, pixel_index;
-            (void)tile_pixel(E, tile, lane, x0, y0, pixel_index);
+            (void)tile_pixel(E, tile, tile_lane, x0, y0, pixel_index);
             if (in_frame) write_pixel(E, L.col, pixel_index);
         }
         // paths = samples started (all of them when depth == 0: camera rays are generated, then ray_color returns untraced)
         L.n_paths = in_frame ? (P.depth == 0 ? (uint32_t)P.spp : (uint32_t)L.s) : 0u;
         L.n_seg = 0;
         flush_counters(E, L, lane, 0ull, 0ull, wave_seg);
-        if (E.tile_cost && lane == 0) E.tile_cost[tile] = cost;
+        if (E.tile_cost && lane == 0) {
+            // a part stands for its tile with the longest part's cost, scaled to what the whole tile would have cost
+            // (parts of 4 pixels measure ~0.8 of the tile's chain), so that the tile is split again next time
+            if (is_part) atomicMax(&E.tile_cost[tile], cost + cost / 4u);
+            else E.tile_cost[tile] = cost;
+        }
 #ifdef PT_TIMELINE
         if (lane == 0 && slot < 131072u) {
             g_timeline[4 * slot] = tl_start;
             g_timeline[4 * slot + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-            g_timeline[4 * slot + 2] = (uint32_t)tile;
+            g_timeline[4 * slot + 2] = (uint32_t)tile | (is_part ? 0x80000000u : 0u);
             g_timeline[4 * slot + 3] = cost;
         }
 #endif
@@ -441,6 +471,33 @@ __global__ void tile_row_cost_kernel(const uint32_t *cost, int tiles_x, unsigned
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// After a launch's costs are sorted (descending): how many of the dearest tiles the NEXT launch of this schedule hands
+// to several waves each.  A tile is split when its chain alone is at least `pct` % of what the whole launch would take
+// with perfectly even work (sum of costs / wave slots the device holds): such a tile, started first, still ends last.
+// (`pct` % of it.)  At most `max_split` tiles, so that the extra, mostly idle waves stay a small share of the slots.  The split tiles'
+// cost entries are zeroed: their parts record max(part cost) with atomicMax.
+__global__ void split_count_kernel(const uint32_t *sorted_cost, const uint32_t *order, uint32_t *cost, unsigned n, unsigned slots_resident,
+                                   unsigned max_split, unsigned pct, uint32_t *n_split)
+{
+    __shared__ unsigned long long part[4];
+    __shared__ uint32_t s_count;
+    unsigned long long sum = 0;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) sum += sorted_cost[i];
+    sum = wave_sum64(sum);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    const unsigned long long total = part[0] + part[1] + part[2] + part[3];
+    const unsigned long long even = total / (slots_resident ? slots_resident : 1u);      // cost units of an evenly spread launch
+    uint32_t mine = 0;
+    if (even != 0) for (unsigned i = threadIdx.x; i < n && i < max_split; i += blockDim.x) mine += 100ull * sorted_cost[i] >= (unsigned long long)pct * even ? 1u : 0u;
+    if (mine) atomicAdd(&s_count, mine);
+    __syncthreads();
+    const uint32_t count = s_count;                                   // sorted descending: those are the first `count` entries
+    for (unsigned i = threadIdx.x; i < count; i += blockDim.x) cost[order[i]] = 0;
+    if (threadIdx.x == 0) *n_split = count;
 }
 
 __global__ void iota_kernel(uint32_t *a, uint32_t *b, unsigned n)
@@ -558,6 +615,7 @@ struct TileSchedule {
     unsigned slots = 0;
     void *base = nullptr;         // one stream-ordered allocation, carved into the buffers below
     uint32_t *order = nullptr, *cost = nullptr, *sorted_cost = nullptr, *iota = nullptr;
+    uint32_t *n_split = nullptr;  // how many of the dearest tiles the next launch splits (split_count_kernel)
     void *temp = nullptr;
     size_t temp_bytes = 0;
     bool has_order = false;
@@ -629,6 +687,9 @@ struct pt_device {
     std::vector<uint32_t *> next_chunks;      // tile counters, 256 per allocation, one 64-byte line each
     size_t next_used = 0;
     int cu_count = 256;
+    int sched_min_blocks = 64;    // launches with fewer workgroups keep raster order (PTAMD_SCHED_MIN_BLOCKS: the fuzzer lowers it)
+    int split_pct = 90;           // ... when its cost is at least this share of an evenly spread launch's (PTAMD_SPLIT_PCT)
+    int sah_split = 16;           // SAH kernel: waves a critically dear tile is handed to (PTAMD_SAH_SPLIT: 0 off, 16, 32, 64)
     int resident_cap = 0;         // persistent kernels: at most this many workgroups per CU (PTAMD_RESIDENT; 0 = what fits)
     struct Resident { const void *kern; size_t lds; int blocks; };
     std::vector<Resident> resident_blocks;      // per kernel and LDS size: workgroups one CU holds (persistent grids)
@@ -638,6 +699,8 @@ struct pt_device {
     // latest row-band launch, for pt_band_costs_read: its schedule (null = no costs recorded) and geometry
     TileSchedule *band_sched = nullptr;
     int band_tiles_x = 0, band_tiles_y = 0, band_rows_last = 0, band_local_rows = 0;
+    TileSchedule *last_sched = nullptr;      // the latest launch's schedule (pt_split_tiles_read), and its stream
+    hipStream_t last_sched_stream = nullptr;
     hipStream_t band_stream = nullptr;
 };
 
@@ -731,6 +794,9 @@ try {
     if (const char *e = getenv("PTAMD_SAH_WAVES")) { const int v = atoi(e); if (v == 5 || v == 6) d->sah_waves = v; }
     if (const char *e = getenv("PTAMD_DEAL_MIN")) { const int v = atoi(e); if (v >= 0 && v <= 65) d->deal_min = v; }
     if (const char *e = getenv("PTAMD_DEAL_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 8192) d->deal_cap = v & ~7; }
+    if (const char *e = getenv("PTAMD_SCHED_MIN_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 1 << 20) d->sched_min_blocks = v; }
+    if (const char *e = getenv("PTAMD_SPLIT_PCT")) { const int v = atoi(e); if (v >= 10 && v <= 1000) d->split_pct = v; }
+    if (const char *e = getenv("PTAMD_SAH_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) d->sah_split = v; }
     if (const char *e = getenv("PTAMD_RESIDENT")) { const int v = atoi(e); if (v >= 1 && v <= 16) d->resident_cap = v; }
     if (const char *e = getenv("PTAMD_FOLD_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 31) d->fold_bits = v; }
     if (const char *e = getenv("PTAMD_COOP")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->coop_mode = v; }
@@ -1197,16 +1263,17 @@ static TileSchedule *schedule_for(pt_device *dev, const RenderParams &P, unsigne
     const size_t bytes = (((size_t)slots * sizeof(uint32_t)) + 255) & ~(size_t)255;
     bool ok = hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t->temp_bytes, t->cost, t->sorted_cost, t->iota, t->order,
                                                            (int)slots, 0, 32, hs) == hipSuccess;
-    if (ok) ok = hipMallocAsync(&t->base, 4 * bytes + std::max<size_t>(t->temp_bytes, 256), hs) == hipSuccess;
+    if (ok) ok = hipMallocAsync(&t->base, 4 * bytes + 256 + std::max<size_t>(t->temp_bytes, 256), hs) == hipSuccess;
     if (ok) {
         uint8_t *b = (uint8_t *)t->base;
         t->order = (uint32_t *)b; t->cost = (uint32_t *)(b + bytes); t->sorted_cost = (uint32_t *)(b + 2 * bytes);
-        t->iota = (uint32_t *)(b + 3 * bytes); t->temp = b + 4 * bytes;
+        t->iota = (uint32_t *)(b + 3 * bytes); t->n_split = (uint32_t *)(b + 4 * bytes); t->temp = b + 4 * bytes + 256;
         ok = hipEventCreateWithFlags(&t->last_use, hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) { (void)hipGetLastError(); free_schedule(t.release(), hs, true); return nullptr; }
     hipLaunchKernelGGL(dev::iota_kernel, dim3((slots + 255) / 256), dim3(256), 0, hs, t->iota, t->order, slots);
     (void)hipMemsetAsync(t->cost, 0, bytes, hs);
+    (void)hipMemsetAsync(t->n_split, 0, 256, hs);
     dev->schedules.push_back(t.get());
     return t.release();
 }
@@ -1291,7 +1358,8 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     hipStream_t hs = (hipStream_t)stream;
     pt_device::LaunchEvents ev;
     TileSchedule *sched = nullptr;
-    P.tile_order = nullptr; P.tile_cost = nullptr;
+    P.tile_order = nullptr; P.tile_cost = nullptr; P.n_split = nullptr; P.split_parts = 16;
+    const bool split = walk == 3 && dev->sah_persistent && dev->sah_split > 0;
     // An error between here and the bookkeeping at the end gives the event pair back and releases the schedule.
     auto fail = [&](pt_status st) {
         std::lock_guard<std::mutex> lk(dev->mu);
@@ -1327,7 +1395,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
             dev->next_used++;
         }
         // one wave slot per tile; tiny launches are not worth a sort
-        if (dev->tile_schedule == 1 && blocks >= 64) sched = schedule_for(dev, P, coop ? blocks : blocks * dev::kWavesPerBlock, hs);
+        if (dev->tile_schedule == 1 && blocks >= (unsigned)dev->sched_min_blocks) sched = schedule_for(dev, P, coop ? blocks : blocks * dev::kWavesPerBlock, hs);
         if (sched) {
             // Pinned while this launch uses it outside the lock (its sort and its last_use record below): eviction
             // in schedule_for() skips busy entries, so another thread's launch can never free it under our feet.
@@ -1343,6 +1411,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
             }
             sched->used = true; sched->last_stream = hs;
             P.tile_order = sched->order; P.tile_cost = sched->cost;
+            if (split) { P.n_split = sched->n_split; P.split_parts = dev->sah_split; }
         }
     }
     PT_HIP_LAUNCH(hipEventRecord(ev.first, hs));
@@ -1361,6 +1430,12 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         // next launch's order: tiles by this launch's cost, dearest first (stable, so ties keep raster order)
         PT_HIP_LAUNCH(hipcub::DeviceRadixSort::SortPairsDescending(sched->temp, sched->temp_bytes, sched->cost, sched->sorted_cost,
                                                                    sched->iota, sched->order, (int)sched->slots, 0, 32, hs));
+        if (split) {
+            const unsigned resident = (unsigned)(dev->cu_count * resident_per_cu(dev, (const void *)kern, lds)) * dev::kWavesPerBlock;
+            hipLaunchKernelGGL(dev::split_count_kernel, dim3(1), dim3(256), 0, hs, sched->sorted_cost, sched->order, sched->cost,
+                               sched->slots, resident, std::max(1u, resident / (4u * (unsigned)dev->sah_split)), (unsigned)dev->split_pct, sched->n_split);
+            PT_HIP_LAUNCH(hipGetLastError());
+        }
         PT_HIP_LAUNCH(hipEventRecord(sched->last_use, hs));
     }
 #undef PT_HIP_LAUNCH
@@ -1368,6 +1443,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         std::lock_guard<std::mutex> lk(dev->mu);
         if (sched) sched->busy--;                // last_use is recorded: from here on hipEventQuery(last_use) tells when it is idle
         dev->last_kernel = choice.name;
+        dev->last_sched = sched; dev->last_sched_stream = hs;
         if (P.band_rows > 0) {
             dev->band_sched = sched; dev->band_tiles_x = P.tiles_x; dev->band_tiles_y = P.tiles_y;
             dev->band_rows_last = P.band_rows; dev->band_local_rows = P.task_h; dev->band_stream = hs;
@@ -1577,6 +1653,27 @@ try {
     unsigned long long h[8];
     PT_HIP(hipMemcpy(h, dev->d_counters, sizeof h, hipMemcpyDeviceToHost));
     out->paths = h[0]; out->segments = h[1]; out->box_tests = h[2]; out->tri_tests = h[3]; out->light_tests = h[4];
+    return PT_OK;
+} PT_CATCH_ALL
+
+pt_status pt_split_tiles_read(pt_device *dev, uint32_t *n_split)
+try {
+    clear_error();
+    if (!dev || !n_split) return set_error(PT_ERR_INVALID, "null argument");
+    *n_split = 0;
+    PT_HIP(hipSetDevice(dev->index));
+    TileSchedule *sched = nullptr;
+    hipStream_t hs;
+    {
+        std::lock_guard<std::mutex> lk(dev->mu);
+        hs = dev->last_sched_stream;
+        for (TileSchedule *t : dev->schedules) if (t == dev->last_sched) sched = t;      // still cached?
+        if (sched) sched->busy++;
+    }
+    if (!sched) return PT_OK;
+    struct Unpin { pt_device *d; TileSchedule *t; ~Unpin() { std::lock_guard<std::mutex> lk(d->mu); t->busy--; } } unpin{dev, sched};
+    PT_HIP(hipMemcpyAsync(n_split, sched->n_split, sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+    PT_HIP(hipStreamSynchronize(hs));
     return PT_OK;
 } PT_CATCH_ALL
 

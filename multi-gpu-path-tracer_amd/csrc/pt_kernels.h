@@ -28,6 +28,8 @@ struct RenderParams {
     unsigned long long *counters;     // 5 x u64: paths, segments, box, tri, light
     const uint32_t *tile_order;       // adaptive schedule: wave slot -> tile (a permutation), or null = raster order
     uint32_t *tile_cost;              // adaptive schedule: shader-clock cost of each tile, written per wave, or null
+    const uint32_t *n_split;          // SAH kernel: how many of the dearest tiles (the first of tile_order) go to `split_parts` waves each, or null
+    int split_parts;                  // 16: parts of 4 x 1 pixels; 32: 2 x 1; 64: single pixels
     uint32_t *tile_next;              // persistent launches: the next slot to hand out (zeroed before the launch), or null
     uint32_t n_slots;                 // persistent launches: slots (tiles) of this launch
     CameraBasis cam;

@@ -367,6 +367,12 @@ class DevicePathTracer:
         capi.check(capi.lib().pt_kernel_time_read(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def splitTiles(self) -> int:
+        """Tiles the next launch of the latest rectangle splits over several waves (SAH kernel; waits for that launch)."""
+        n = C.c_uint32()
+        capi.check(capi.lib().pt_split_tiles_read(self._h, C.byref(n)))
+        return n.value
+
     def kernelName(self) -> str:
         """Symbol of the kernel the latest render launch ran (what a rocprofv3 kernel trace shows)."""
         buf = C.create_string_buffer(256)

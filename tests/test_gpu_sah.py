@@ -50,6 +50,37 @@ def test_sah_closest_hits_equal_reference_traversal(pt, box_scene, duck_scene, g
     assert hits > n // 2
 
 
+@pytest.mark.parametrize("name,parts", [("box", 16), ("box", 64), ("duck", 16), ("duck", 4)])
+def test_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, duck_oracle, gpu_device, monkeypatch, name, parts):
+    """The SAH kernel hands its critically dear tiles to several waves (a few pixels each) from the third launch of a
+    rectangle on: which wave renders a pixel must never change it.  PTAMD_SPLIT_PCT = 10 makes every launch's dearest
+    tiles "critical", so the split paths run on these small frames; every frame must equal the oracle's, with the
+    same counters (box / triangle tests included: per pixel the walk is the same)."""
+    monkeypatch.setenv("PTAMD_SPLIT_PCT", "10")
+    monkeypatch.setenv("PTAMD_SAH_SPLIT", str(parts))
+    scene, cam, oracle = (box_scene, BOX_CAMERA, box_oracle) if name == "box" else (duck_scene, DUCK_CAMERA, duck_oracle)
+    W, H, spp, depth = 200, 168, 3, 5               # 25 x 21 tiles: enough workgroups for a cost-ordered schedule
+    tr, fb = _tracer(pt, scene, cam, W, H, spp, depth, sah=True)
+    ref = oracle.render(cam, W, H, spp, depth, threads=8)
+    first = None
+    split_seen = 0
+    for frame in range(5):
+        tr.resetCounters()
+        tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+        assert "sah" in tr.kernelName()
+        cnt = tr.readCounters()
+        if first is None:
+            first = cnt
+        assert cnt == first, "frame %d: counters moved" % frame
+        assert np.array_equal(fb.rgb_host(), ref[0]) and np.array_equal(fb.yuv_host(), ref[1]), "frame %d" % frame
+        n = tr.splitTiles()                         # what the NEXT launch will split
+        if frame >= 1:
+            assert n > 0
+        split_seen = max(split_seen, n)
+    print("%s, %d parts: %d tiles split" % (name, parts, split_seen))
+    tr.close()
+
+
 @pytest.mark.parametrize("name,W,H,spp,depth", [("box", 160, 90, 8, 8), ("duck", 96, 54, 3, 8)])
 def test_sah_images_match_oracle(pt, box_scene, duck_scene, gpu_device, name, W, H, spp, depth):
     import os

@@ -60,6 +60,11 @@ def one(seed):
     # the dealt walk's split between dealt and in-place leaves, and its list capacity, are read at pt_device_create
     os.environ["PTAMD_DEAL_MIN"] = str(int(rng.choice([0, 8, 24, 48, 56, 65])))
     os.environ["PTAMD_DEAL_CAP"] = str(int(rng.choice([64, 128, 768])))
+    # so are: from how many workgroups on a launch gets a cost-ordered schedule (default 64: never on frames this small),
+    # and the SAH kernel's split of its dearest tiles (10 % of an even launch's cost: always some)
+    os.environ["PTAMD_SCHED_MIN_BLOCKS"] = str(int(rng.choice([1, 2, 64])))
+    os.environ["PTAMD_SPLIT_PCT"] = str(int(rng.choice([10, 90])))
+    os.environ["PTAMD_SAH_SPLIT"] = str(int(rng.choice([0, 4, 16, 64])))
     fb = pt.Framebuffer(pt.Resolution(W, H))
     tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, pt.CameraConfig(cam[0], cam[1], cam[2], cam[3]),
                              legacyMaterials=legacy, spheres=spheres)
@@ -97,6 +102,14 @@ def one(seed):
         tr2 = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb2, pt.CameraConfig(cam[0], cam[1], cam[2], cam[3]))
         tr2.setBvhMode(1)
         tr2.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr2.waitForRenderTask()
+        one_rgb, one_yuv, one_cnt = fb2.rgb_host().copy(), fb2.yuv_host().copy(), None
+        for _ in range(3):        # later launches run in cost order with the dearest tiles split over several waves:
+            tr2.resetCounters()   # a gate -- whatever wave renders a pixel, the frame and the counters stay the same
+            tr2.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr2.waitForRenderTask()
+            cnt = tr2.readCounters()
+            assert np.array_equal(fb2.rgb_host(), one_rgb) and np.array_equal(fb2.yuv_host(), one_yuv), "SAH frames differ between launches"
+            assert one_cnt is None or cnt == one_cnt, "SAH counters differ between launches"
+            one_cnt = cnt
         diff = int((fb2.rgb_host() != ref[0]).sum())
         SAH_STATS["cases"] += 1; SAH_STATS["bytes"] += ref[0].size
         SAH_STATS["cases_differ"] += diff > 0; SAH_STATS["bytes_differ"] += diff
