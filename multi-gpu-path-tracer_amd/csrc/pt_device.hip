@@ -131,6 +131,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
     const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
     const ShadeViewLds V = stage_shade_lds(P, LL.tail, tid, kBlock);      // the host picks this kernel only when the tables fit
     const DealView D = deal_carve(P, V.end, tid, kBlock);
+    // Split tiles (see render_sah_body): here a trip's cost is mostly the wave's (box walk, shading), so a part of 16
+    // pixels still costs ~0.65 of the tile per trip -- worth it only when the tile's chain bounds the launch, i.e. for
+    // a rank's share of a multi-GPU frame, where there are fewer tiles than wave slots (split_count_kernel decides).
+    const uint32_t parts = (uint32_t)P.split_parts;
+    uint32_t n_split = 0, n_slots_all = 0;
+    {
+        KernargParams &K = *fresh_kernarg();
+        if (K.n_split) n_split = K.n_split[0];
+        n_slots_all = K.n_slots + n_split * (parts - 1u);
+    }
     // Persistent waves: the launch has as many workgroups as the device holds at once, and every WAVE takes its next tile
     // from a counter when its own tile is done.  With one workgroup per four tiles a finished wave's slot stayed empty until
     // its three siblings were done too (5 % of the slots of a C2 frame), and the shading tables were staged 8 100 times.
@@ -139,13 +149,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
         uint32_t slot = 0;
         if (lane == 0) slot = atomicAdd(K.tile_next, 1u);
         slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-        if (slot >= K.n_slots) break;                      // every wave gets here: the counter only grows
+        if (slot >= n_slots_all) break;                    // every wave gets here: the counter only grows
 #ifdef PT_TIMELINE
         const uint32_t tl_start = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
-        const int tile = K.tile_order ? (int)K.tile_order[slot] : (int)slot;
+        const SlotWork sw = slot_work(K, slot, n_split, parts, lane);
+        const int tile = sw.tile;
         int x, y, pixel_index;
-        const bool in_frame = tile_pixel(K, tile, lane, x, y, pixel_index);
+        const bool in_frame = tile_pixel(K, tile, sw.tile_lane, x, y, pixel_index) && sw.lane_on;
         PathState L;
         path_init(L, P, pixel_index);
         bool alive = in_frame && P.depth > 0;
@@ -186,12 +197,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
         L.n_paths = in_frame ? (P.depth == 0 ? (uint32_t)P.spp : (uint32_t)L.s) : 0u;      // samples started (depth 0: rays generated, untraced)
         L.n_seg = 0;
         flush_counters(E, L, lane, wave_box, wave_tri, wave_seg);
-        if (E.tile_cost && lane == 0) E.tile_cost[tile] = trips;
+        if (E.tile_cost && lane == 0) {
+            if (sw.is_part) atomicMax(&E.tile_cost[tile], trips);      // a tile's trips = those of its busiest pixel, in whichever part
+            else E.tile_cost[tile] = trips;
+        }
 #ifdef PT_TIMELINE
         if (lane == 0 && slot < 131072u) {
             g_timeline[4 * slot] = tl_start;
             g_timeline[4 * slot + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-            g_timeline[4 * slot + 2] = (uint32_t)tile;
+            g_timeline[4 * slot + 2] = (uint32_t)tile | (sw.is_part ? 0x80000000u : 0u);
             g_timeline[4 * slot + 3] = trips;
         }
 #endif
@@ -308,18 +322,9 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 #ifdef PT_TIMELINE
         const uint32_t tl_start = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
-        const bool is_part = slot < n_split * parts;
-        const uint32_t entry = is_part ? slot / parts : slot - n_split * (parts - 1u);
-        const int tile = K.tile_order ? (int)K.tile_order[entry] : (int)entry;
-        // lane -> pixel of the 8 x 8 tile: all 64, or the 64 / parts consecutive ones of part (slot % parts)
-        int tile_lane = lane;
-        bool lane_on = true;
-        if (is_part) {
-            const uint32_t per = 64u / parts;
-            tile_lane = (int)((slot % parts) * per + (uint32_t)lane);
-            lane_on = (uint32_t)lane < per;
-            if (!lane_on) tile_lane = 0;
-        }
+        const SlotWork sw = slot_work(K, slot, n_split, parts, lane);
+        const int tile = sw.tile, tile_lane = sw.tile_lane;
+        const bool lane_on = sw.lane_on, is_part = sw.is_part;
         int x, y;
         bool in_frame;
         PathState L;
@@ -474,12 +479,14 @@ __global__ void tile_row_cost_kernel(const uint32_t *cost, int tiles_x, unsigned
 }
 
 // After a launch's costs are sorted (descending): how many of the dearest tiles the NEXT launch of this schedule hands
-// to several waves each.  A tile is split when its chain alone is at least `pct` % of what the whole launch would take
-// with perfectly even work (sum of costs / wave slots the device holds): such a tile, started first, still ends last.
-// (`pct` % of it.)  At most `max_split` tiles, so that the extra, mostly idle waves stay a small share of the slots.  The split tiles'
-// cost entries are zeroed: their parts record max(part cost) with atomicMax.
-__global__ void split_count_kernel(const uint32_t *sorted_cost, const uint32_t *order, uint32_t *cost, unsigned n, unsigned slots_resident,
-                                   unsigned max_split, unsigned pct, uint32_t *n_split)
+// to several waves each.  Nothing is split unless the dearest tile is critical: its chain alone is at least `pct` % of
+// what the whole launch would take with perfectly even work (sum of costs / wave slots the device holds) -- such a tile,
+// started first, still ends last.  Then every tile dearer than `ratio` % of the dearest is split (a part's chain is
+// about `ratio` % of its tile's, so splitting cheaper tiles could not shorten the launch), at most `max_split` of them
+// (the extra, partly idle waves must stay a small share of the slots: filling an under-occupied device with parts
+// slows every chain on it).
+__global__ void split_count_kernel(const uint32_t *sorted_cost, unsigned n, unsigned slots_resident,
+                                   unsigned max_split, unsigned pct, unsigned ratio, uint32_t *n_split)
 {
     __shared__ unsigned long long part[4];
     __shared__ uint32_t s_count;
@@ -491,13 +498,21 @@ __global__ void split_count_kernel(const uint32_t *sorted_cost, const uint32_t *
     __syncthreads();
     const unsigned long long total = part[0] + part[1] + part[2] + part[3];
     const unsigned long long even = total / (slots_resident ? slots_resident : 1u);      // cost units of an evenly spread launch
+    const unsigned long long top = n ? sorted_cost[0] : 0u;
     uint32_t mine = 0;
-    if (even != 0) for (unsigned i = threadIdx.x; i < n && i < max_split; i += blockDim.x) mine += 100ull * sorted_cost[i] >= (unsigned long long)pct * even ? 1u : 0u;
+    if (top != 0 && 100ull * top >= (unsigned long long)pct * even)
+        for (unsigned i = threadIdx.x; i < n && i < max_split; i += blockDim.x) mine += 100ull * sorted_cost[i] > (unsigned long long)ratio * top ? 1u : 0u;
     if (mine) atomicAdd(&s_count, mine);
     __syncthreads();
-    const uint32_t count = s_count;                                   // sorted descending: those are the first `count` entries
+    if (threadIdx.x == 0) *n_split = s_count;                         // sorted descending: those are the first entries of the order
+}
+
+// Before a launch that splits tiles: their cost entries start from zero (the parts record with atomicMax).  Not done by
+// split_count_kernel, because pt_band_costs_read and the next sort still read the finished launch's costs after it.
+__global__ void split_reset_kernel(const uint32_t *order, uint32_t *cost, const uint32_t *n_split)
+{
+    const uint32_t count = *n_split;
     for (unsigned i = threadIdx.x; i < count; i += blockDim.x) cost[order[i]] = 0;
-    if (threadIdx.x == 0) *n_split = count;
 }
 
 __global__ void iota_kernel(uint32_t *a, uint32_t *b, unsigned n)
@@ -688,7 +703,9 @@ struct pt_device {
     size_t next_used = 0;
     int cu_count = 256;
     int sched_min_blocks = 64;    // launches with fewer workgroups keep raster order (PTAMD_SCHED_MIN_BLOCKS: the fuzzer lowers it)
-    int split_pct = 90;           // ... when its cost is at least this share of an evenly spread launch's (PTAMD_SPLIT_PCT)
+    int split_ratio = 0;          // ... and every tile dearer than this share of the dearest (0: 65 % dealt, 80 % SAH; PTAMD_SPLIT_RATIO)
+    int split_pct = 0;           // ... when the dearest costs at least this % of an evenly spread launch's share per slot (0: 110 dealt, 90 SAH; PTAMD_SPLIT_PCT)
+    int deal_split = 4;           // dealt kernel: likewise (PTAMD_DEAL_SPLIT: 0 off, 2, 4, 8)
     int sah_split = 16;           // SAH kernel: waves a critically dear tile is handed to (PTAMD_SAH_SPLIT: 0 off, 16, 32, 64)
     int resident_cap = 0;         // persistent kernels: at most this many workgroups per CU (PTAMD_RESIDENT; 0 = what fits)
     struct Resident { const void *kern; size_t lds; int blocks; };
@@ -795,7 +812,9 @@ try {
     if (const char *e = getenv("PTAMD_DEAL_MIN")) { const int v = atoi(e); if (v >= 0 && v <= 65) d->deal_min = v; }
     if (const char *e = getenv("PTAMD_DEAL_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 8192) d->deal_cap = v & ~7; }
     if (const char *e = getenv("PTAMD_SCHED_MIN_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 1 << 20) d->sched_min_blocks = v; }
+    if (const char *e = getenv("PTAMD_SPLIT_RATIO")) { const int v = atoi(e); if (v >= 1 && v <= 100) d->split_ratio = v; }
     if (const char *e = getenv("PTAMD_SPLIT_PCT")) { const int v = atoi(e); if (v >= 10 && v <= 1000) d->split_pct = v; }
+    if (const char *e = getenv("PTAMD_DEAL_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 2 || v == 4 || v == 8) d->deal_split = v; }
     if (const char *e = getenv("PTAMD_SAH_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) d->sah_split = v; }
     if (const char *e = getenv("PTAMD_RESIDENT")) { const int v = atoi(e); if (v >= 1 && v <= 16) d->resident_cap = v; }
     if (const char *e = getenv("PTAMD_FOLD_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 31) d->fold_bits = v; }
@@ -1359,7 +1378,8 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     pt_device::LaunchEvents ev;
     TileSchedule *sched = nullptr;
     P.tile_order = nullptr; P.tile_cost = nullptr; P.n_split = nullptr; P.split_parts = 16;
-    const bool split = walk == 3 && dev->sah_persistent && dev->sah_split > 0;
+    const int split_parts = walk == 4 ? dev->deal_split : (walk == 3 && dev->sah_persistent) ? dev->sah_split : 0;
+    const bool split = split_parts > 0;
     // An error between here and the bookkeeping at the end gives the event pair back and releases the schedule.
     auto fail = [&](pt_status st) {
         std::lock_guard<std::mutex> lk(dev->mu);
@@ -1411,8 +1431,12 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
             }
             sched->used = true; sched->last_stream = hs;
             P.tile_order = sched->order; P.tile_cost = sched->cost;
-            if (split) { P.n_split = sched->n_split; P.split_parts = dev->sah_split; }
+            if (split) { P.n_split = sched->n_split; P.split_parts = split_parts; }
         }
+    }
+    if (split && sched) {
+        hipLaunchKernelGGL(dev::split_reset_kernel, dim3(1), dim3(256), 0, hs, sched->order, sched->cost, sched->n_split);
+        PT_HIP_LAUNCH(hipGetLastError());
     }
     PT_HIP_LAUNCH(hipEventRecord(ev.first, hs));
     if (persistent) {
@@ -1432,8 +1456,10 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
                                                                    sched->iota, sched->order, (int)sched->slots, 0, 32, hs));
         if (split) {
             const unsigned resident = (unsigned)(dev->cu_count * resident_per_cu(dev, (const void *)kern, lds)) * dev::kWavesPerBlock;
-            hipLaunchKernelGGL(dev::split_count_kernel, dim3(1), dim3(256), 0, hs, sched->sorted_cost, sched->order, sched->cost,
-                               sched->slots, resident, std::max(1u, resident / (4u * (unsigned)dev->sah_split)), (unsigned)dev->split_pct, sched->n_split);
+            // extra waves the split may add: the wave slots this launch leaves empty, or an eighth of all of them
+            const unsigned spare = std::max(resident / 8u, resident > sched->slots ? resident - sched->slots : 0u);
+            hipLaunchKernelGGL(dev::split_count_kernel, dim3(1), dim3(256), 0, hs, sched->sorted_cost, sched->slots, resident, std::max(1u, spare / (unsigned)(split_parts - 1)), (unsigned)(dev->split_pct > 0 ? dev->split_pct : walk == 4 ? 110 : 90),
+                               (unsigned)(dev->split_ratio > 0 ? dev->split_ratio : walk == 4 ? 65 : 80), sched->n_split);
             PT_HIP_LAUNCH(hipGetLastError());
         }
         PT_HIP_LAUNCH(hipEventRecord(sched->last_use, hs));

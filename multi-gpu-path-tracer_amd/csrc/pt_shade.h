@@ -558,6 +558,32 @@ __device__ __forceinline__ KernargParams *fresh_kernarg()
     return k;
 }
 
+// What a persistent wave renders for the slot it drew from the launch's counter.  The first n_split entries of the tile
+// order are handed out as `parts` slots each (part q = the 64 / parts consecutive lanes' pixels q * 64 / parts ... of the
+// 8 x 8 tile, i.e. whole pixel rows or pieces of one); every later entry is a whole tile.
+struct SlotWork {
+    int tile;          // index into the launch's tile grid
+    int tile_lane;     // which of the tile's 64 pixels this lane renders (lane & 7 = column, lane >> 3 = row)
+    bool lane_on;      // false: this lane has no pixel (a part uses only the first 64 / parts lanes)
+    bool is_part;
+};
+template <class Params>
+__device__ __forceinline__ SlotWork slot_work(Params &K, uint32_t slot, uint32_t n_split, uint32_t parts, int lane)
+{
+    SlotWork w;
+    w.is_part = slot < n_split * parts;
+    const uint32_t entry = w.is_part ? slot / parts : slot - n_split * (parts - 1u);
+    w.tile = K.tile_order ? (int)K.tile_order[entry] : (int)entry;
+    w.tile_lane = lane;
+    w.lane_on = true;
+    if (w.is_part) {
+        const uint32_t per = 64u / parts;
+        w.lane_on = (uint32_t)lane < per;
+        w.tile_lane = w.lane_on ? (int)((slot % parts) * per + (uint32_t)lane) : 0;
+    }
+    return w;
+}
+
 // Tile of this wave: its launch slot, or what the adaptive schedule assigns to that slot.
 __device__ __forceinline__ int wave_tile(const RenderParams &P, int tid)
 {

@@ -64,6 +64,32 @@ def test_band_tasks_on_several_streams_equal_whole_frame(pt, duck_scene, duck_or
     tr.close()
 
 
+@pytest.mark.parametrize("parts", [2, 4, 8])
+def test_dealt_kernel_split_tiles_never_change_a_byte(pt, box_scene, box_oracle, gpu_device, monkeypatch, parts):
+    """The dealt kernel, like the SAH kernel (test_gpu_sah.py), hands the dearest tiles of a launch whose longest chain
+    bounds it to several waves of a few pixel rows each.  PTAMD_SPLIT_PCT = 10 makes that the case on this small frame;
+    every frame -- raster order, cost order, split tiles -- must equal the oracle's, counters included."""
+    monkeypatch.setenv("PTAMD_SPLIT_PCT", "10")
+    monkeypatch.setenv("PTAMD_DEAL_SPLIT", str(parts))
+    W, H, spp, depth = 200, 168, 3, 5
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
+    ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    seen = 0
+    for frame in range(5):
+        fb.rgb.zero_(); fb.yuv.zero_()
+        tr.resetCounters()
+        tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+        assert "dealt" in tr.kernelName()
+        cnt = tr.readCounters()
+        assert np.array_equal(fb.rgb_host(), ref[0]) and np.array_equal(fb.yuv_host(), ref[1]), "frame %d" % frame
+        for k in ("paths", "segments", "box_tests", "tri_tests", "light_tests"):      # the reference tree: the oracle's counts
+            assert cnt[k] == ref[2][k], (frame, k, cnt[k], ref[2][k])
+        seen = max(seen, tr.splitTiles())
+    assert seen > 0
+    tr.close()
+
+
 @pytest.mark.parametrize("bvh,kernel", [(0, "dealt"), (1, "sah")])
 def test_persistent_kernels_with_many_launches_in_flight(pt, box_scene, box_oracle, gpu_device, bvh, kernel):
     """The dealt and SAH kernels are persistent: a launch's waves take their tiles from a counter of that launch.  Many
