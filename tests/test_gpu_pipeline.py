@@ -90,6 +90,30 @@ def test_dealt_kernel_split_tiles_never_change_a_byte(pt, box_scene, box_oracle,
     tr.close()
 
 
+def test_split_tiles_in_band_launches_keep_frame_and_band_costs(pt, box_scene, box_oracle, gpu_device, monkeypatch):
+    """A rank's band launch (what the multi-GPU path renders) with its dearest tiles split: the union over ranks is the
+    oracle's frame on every frame, and the per-band costs the dealer is fed do not move when tiles start being split
+    (a dealt tile's cost is the trip count of its busiest pixel, whichever part holds that pixel)."""
+    monkeypatch.setenv("PTAMD_SPLIT_PCT", "10")
+    W, H, spp, depth, band, world = 320, 200, 2, 4, 8, 2
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
+    ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    costs, splits = [], []
+    for frame in range(4):
+        fb.rgb.zero_(); fb.yuv.zero_()
+        per_rank = []
+        for rank in range(world):
+            tr.renderBandsAsync(band, world, rank); tr.waitForRenderTask()
+            per_rank.append(tr.bandCosts())
+            splits.append(tr.splitTiles())
+        assert np.array_equal(fb.rgb_host(), ref[0]) and np.array_equal(fb.yuv_host(), ref[1]), "frame %d" % frame
+        costs.append(per_rank)
+    assert max(splits) > 0
+    assert all(c == costs[0] for c in costs[1:])
+    tr.close()
+
+
 @pytest.mark.parametrize("bvh,kernel", [(0, "dealt"), (1, "sah")])
 def test_persistent_kernels_with_many_launches_in_flight(pt, box_scene, box_oracle, gpu_device, bvh, kernel):
     """The dealt and SAH kernels are persistent: a launch's waves take their tiles from a counter of that launch.  Many
