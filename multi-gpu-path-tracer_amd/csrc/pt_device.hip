@@ -332,6 +332,9 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
         SahWalk W;
         sah_begin(W, mk3(1.0f, 1.0f, 1.0f), 0.0f);
         W.pair = kNoPair;                                      // nobody walks yet
+#ifdef PT_STALE
+        W.stale = W.visits = 0;
+#endif
         bool alive = in_frame && P.depth > 0;
         uint32_t cost = 0;                                    // wave-uniform: micro-step trips + 8 per outer trip
         // Box / triangle tests are counted per lane (one masked add per micro-step; a wave-level sum of the vote's popcounts
@@ -380,6 +383,12 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
         L.n_paths = in_frame ? (P.depth == 0 ? (uint32_t)P.spp : (uint32_t)L.s) : 0u;
         L.n_seg = 0;
         flush_counters(E, L, lane, 0ull, 0ull, wave_seg);
+#ifdef PT_STALE
+        {
+            const uint32_t s5 = wave_sum(W.stale), s6 = wave_sum(W.visits);
+            if (lane == 0) { atomicAdd(&E.counters[5], (unsigned long long)s5); atomicAdd(&E.counters[6], (unsigned long long)s6); }
+        }
+#endif
         if (E.tile_cost && lane == 0) {
             // a part stands for its tile with the longest part's cost, scaled to what the whole tile would have cost
             // (parts of 4 pixels measure ~0.8 of the tile's chain), so that the tile is split again next time

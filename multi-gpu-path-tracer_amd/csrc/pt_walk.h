@@ -515,6 +515,9 @@ struct SahWalk {
                                   // recomputes them for the winner, same arithmetic, same operands -> the same bits
     v3 inv;
     uint32_t k0, n0, k1, n1;      // pending leaf triangles (byte offset, count): range 0 first, then range 1
+#ifdef PT_STALE
+    uint32_t stale, visits;       // diagnostic build: node visits that found both children beyond the closest hit / all visits
+#endif
     // `pair` == kNoPair: no node is left to visit.  (A register compare a vote can use directly: a bool carried across
     // trips is materialised as 0 / 1 and compared again for every ballot.)
 };
@@ -581,12 +584,18 @@ __device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W,
     const v3 inv = W.inv;
     float tnl, tnr;
     bool hl, hr;
+#ifdef PT_STALE
+    bool g_l = false, g_r = false;
+#endif
     {
         float t1 = (a.x - o.x) * inv.x, t2 = (a.y - o.x) * inv.x, t3 = (a.z - o.y) * inv.y, t4 = (a.w - o.y) * inv.y;
         float t5 = (b.x - o.z) * inv.z, t6 = (b.y - o.z) * inv.z;
         tnl = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
         float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
         hl = (tf >= fmaxf(tnl, 0.0f)) & (tnl <= W.tbest);
+#ifdef PT_STALE
+        g_l = tf >= fmaxf(tnl, 0.0f);
+#endif
     }
     {
         float t1 = (b.z - o.x) * inv.x, t2 = (b.w - o.x) * inv.x, t3 = (c.x - o.y) * inv.y, t4 = (c.y - o.y) * inv.y;
@@ -594,7 +603,14 @@ __device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W,
         tnr = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
         float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
         hr = (tf >= fmaxf(tnr, 0.0f)) & (tnr <= W.tbest);
+#ifdef PT_STALE
+        g_r = tf >= fmaxf(tnr, 0.0f);
+#endif
     }
+#ifdef PT_STALE
+    W.stale += (!hl && !hr && (g_l || g_r)) ? 1u : 0u;      // visited only to find both children beyond the closest hit
+    W.visits++;
+#endif
     n_box += 2;
     // leaf children -> pending triangle ranges
     W.k0 = llink; W.n0 = (hl && lcnt) ? lcnt : 0u;
