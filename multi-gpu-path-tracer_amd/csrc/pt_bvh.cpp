@@ -308,6 +308,7 @@ void build_reference_bvh(const float *positions9, size_t n_tris, RefBvh &out)
 // resolves them.
 // ===================================================================================
 #include <cfloat>
+#include <cstring>
 #include <future>
 
 namespace pt {
@@ -503,6 +504,99 @@ void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out)
         if (p.lcnt) out.max_leaf = std::max(out.max_leaf, p.lcnt);
         if (p.rcnt) out.max_leaf = std::max(out.max_leaf, p.rcnt);
     }
+}
+
+
+namespace {
+struct QuadChild { float b[6]; uint32_t link, cnt; };
+
+struct QuadCollapse {
+    const std::vector<NodePair> &pairs;
+    std::vector<NodePair> &out;          // two per quad
+    bool ok = true;
+    QuadCollapse(const std::vector<NodePair> &p, std::vector<NodePair> &o) : pairs(p), out(o) {}
+
+    QuadChild child(uint32_t p, int side) const
+    {
+        const NodePair &n = pairs[p];
+        QuadChild c;
+        const float *f = side ? &n.rxmin : &n.lxmin;          // six consecutive floats per side
+        for (int k = 0; k < 6; k++) c.b[k] = f[k];
+        c.link = side ? n.rlink : n.llink; c.cnt = side ? n.rcnt : n.lcnt;
+        return c;
+    }
+    static float half_area(const QuadChild &c)
+    {
+        const float ex = c.b[1] - c.b[0], ey = c.b[3] - c.b[2], ez = c.b[5] - c.b[4];
+        return ex * ey + ey * ez + ez * ex;
+    }
+    // Returns the quad's index; *need = the most stack entries a walk below (and including) this quad can hold.
+    uint32_t make(uint32_t p, uint32_t *need)
+    {
+        const uint32_t qi = (uint32_t)(out.size() / 2);
+        out.emplace_back(); out.emplace_back();
+        QuadChild ch[4];
+        int n = 2;
+        ch[0] = child(p, 0); ch[1] = child(p, 1);
+        while (n < 4) {
+            int pick = -1;
+            float best = -1.0f;
+            for (int i = 0; i < n; i++) {
+                if (ch[i].cnt != 0) continue;                  // leaves (and the empty child of a leaf root) stay
+                const float a = half_area(ch[i]);
+                if (pick < 0 || a > best) { pick = i; best = a; }
+            }
+            if (pick < 0) break;
+            const uint32_t pp = ch[pick].link;
+            ch[pick] = child(pp, 0);
+            ch[n++] = child(pp, 1);
+        }
+        // An absent child (fewer than four, or the empty half of a leaf root, whose inverted box the slab test would
+        // ACCEPT: every axis interval of (+inf, -inf) comes out as (-inf, +inf)) gets a box with min = max = +inf on
+        // every axis: per axis both plane distances are the same infinity, so the entry distance is +inf or the exit
+        // distance -inf -- never entered, whatever the ray.
+        uint32_t links[4] = {1u, 1u, 1u, 1u};
+        bool absent[4] = {true, true, true, true};
+        uint32_t deepest = 0;
+        int real = 0;
+        for (int i = 0; i < n; i++) {
+            if (!(ch[i].b[0] <= ch[i].b[1])) continue;         // the empty half of a leaf root
+            absent[i] = false;
+            real++;
+            if (ch[i].cnt == 0) {
+                uint32_t sub = 0;
+                const uint32_t q = make(ch[i].link, &sub);
+                links[i] = q * 128u;
+                deepest = std::max(deepest, sub);
+            } else {
+                if (ch[i].cnt > 15u) ok = false;
+                links[i] = ch[i].link * (uint32_t)sizeof(TriIsect) | (ch[i].cnt & 15u);
+            }
+        }
+        float f[24];
+        for (int i = 0; i < 4; i++)
+            for (int k = 0; k < 6; k++) f[6 * i + k] = absent[i] ? INFINITY : ch[i].b[k];
+        NodePair &h0 = out[2 * (size_t)qi], &h1 = out[2 * (size_t)qi + 1];
+        memcpy(&h0.lxmin, f, 12 * sizeof(float));
+        memcpy(&h1.lxmin, f + 12, 12 * sizeof(float));
+        h0.llink = links[0]; h0.lcnt = links[1]; h0.rlink = links[2]; h0.rcnt = links[3];
+        h1.llink = h1.lcnt = h1.rlink = h1.rcnt = 0;
+        *need = (uint32_t)std::max(real - 1, 0) + deepest;
+        return qi;
+    }
+};
+} // namespace
+
+bool collapse_sah_quads(const SahBvh &in, std::vector<NodePair> &quads2, uint32_t &max_stack)
+{
+    static_assert(sizeof(NodePair) == 64, "a QuadNode is two NodePair-sized halves");
+    quads2.clear();
+    quads2.reserve(in.pairs.size() + 2);
+    QuadCollapse c(in.pairs, quads2);
+    uint32_t need = 0;
+    (void)c.make(0, &need);
+    max_stack = need + 1;
+    return c.ok && (quads2.size() / 2) * 128ull < (1ull << 32);
 }
 
 } // namespace pt

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
 // are walking -- until at least half of those that were walking have finished -- and (3) shading
 // the finished ones, while the stragglers keep their traversal state (pair, LDS stack, closest
 // hit) across trips.  Per ray the sequence of tests is exactly traverse_sah's.
+template <bool kWide>
 __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 {
     extern __shared__ float4 lds_raw[];
@@ -365,9 +366,15 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
                 // rather than making the whole wave run its block for a few lanes
                 const int want_tri = pt_popc(tri_mask), want_node = pt_popc(pair_mask & ~tri_mask);
                 if (want_tri >= want_node) {
-                    if (sah_wants_tri(W)) (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
+                    if (sah_wants_tri(W)) {
+                        if (kWide) (void)sahw_tri_step(P, W, L.ro, L.rd, 0.001f, stack, kBlock, L.n_tri);
+                        else (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
+                    }
                 } else {
-                    if (sah_wants_node(W)) (void)sah_node_step(P, W, L.ro, L.rd, stack, kBlock, L.n_box);
+                    if (sah_wants_node(W)) {
+                        if (kWide) (void)sahw_node_step(P, W, L.ro, L.rd, stack, kBlock, L.n_box);
+                        else (void)sah_node_step(P, W, L.ro, L.rd, stack, kBlock, L.n_box);
+                    }
                 }
                 cost++;
             }
@@ -410,8 +417,10 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 // and triangles stay in cache are issue-bound and gain from a sixth wave even at the price of a few
 // spills (C3 143 -> 136 ms); the 1 GB terrain is bound by memory latency per dependent step and loses
 // to the spills (C4 84 -> 88 ms), so it keeps the natural allocation.
-__global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P) { render_sah_body(P); }
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_sah6(RenderParams P) { render_sah_body(P); }
+__global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P) { render_sah_body<false>(P); }
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_sah6(RenderParams P) { render_sah_body<false>(P); }
+// the 4-wide form of the tree (RenderParams::sah == 2)
+__global__ __launch_bounds__(kBlock) void render_kernel_sahw(RenderParams P) { render_sah_body<true>(P); }
 
 // ---- known-answer kernels (bit-exactness contract) -----------------------------------
 __global__ void kat_arith_kernel(int op, const float *a, const float *b, float *o0, float *o1, size_t n)
@@ -672,6 +681,8 @@ struct pt_device {
     bool packed_queue = false;    // leaf-queue entries fit one dword (< 65536 triangles)
     int walk = 0;                 // traversal schedule: 0 per-lane, 1 uniform/mask, 2 uniform/stack, 3 SAH tree
     bool sah = false;             // uploaded with the opt-in SAH tree instead of the reference topology
+    bool sah_wide = true;         // upload the SAH tree in its 4-wide form (PTAMD_SAH_WIDE=0: the pair form)
+    bool sah_wide_on = false;     // ... and the uploaded scene has it
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
     int spec_pct = -1;            // ... and leaves the walk loop when <= this % of the walkers remain; -1 = by scene size (fill_params)
     int deal_cap = 768, deal_min = 48;   // dealt walk (kWalk 4): item list capacity per wave; in-place threshold (lanes)
@@ -814,6 +825,7 @@ try {
     // diagnostic A/B switches for the sweeps under tools/ (DESIGN.md section 4b); none changes a byte of output,
     // out-of-range values are ignored
     if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;
+    if (const char *e = getenv("PTAMD_SAH_WIDE")) d->sah_wide = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 99) d->spec_pct = v; }   // 100 would leave the walk loop before its first step
     if (const char *e = getenv("PTAMD_DEAL")) d->deal_auto = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_LRPT")) d->lrpt = atoi(e) != 0;
@@ -943,6 +955,7 @@ try {
         for (size_t i = 0; i < n; i++) bvh.indices[i] = (int)i;
     }
     SahBvh sahbvh;
+    bool sah_wide_on = false;
     if (sah) {
         build_sah_bvh(pos.data(), n, sahbvh);
         if (sahbvh.max_stack > 64) return set_error(PT_ERR_STACK, "SAH tree deeper than 64 levels");
@@ -1012,10 +1025,16 @@ try {
         // the SAH walk addresses records by 32-bit byte offsets (pt_walk.h SahWalk): scale the builder's links
         if (n * sizeof(TriIsect) >= ((size_t)1 << 32) || sahbvh.pairs.size() * sizeof(NodePair) >= ((size_t)1 << 32))
             return set_error(PT_ERR_UNSUPPORTED, "SAH tree: node and triangle records are addressed by 32-bit byte offsets (< 89 M triangles)");
-        pairs = sahbvh.pairs;
-        for (NodePair &q : pairs) {
-            q.llink *= q.lcnt ? (uint32_t)sizeof(TriIsect) : (uint32_t)sizeof(NodePair);
-            q.rlink *= q.rcnt ? (uint32_t)sizeof(TriIsect) : (uint32_t)sizeof(NodePair);
+        uint32_t wide_stack = 0;
+        sah_wide_on = dev->sah_wide && collapse_sah_quads(sahbvh, pairs, wide_stack) && wide_stack <= 64;
+        if (sah_wide_on) {
+            sahbvh.max_stack = wide_stack;       // entries a walk of the 4-wide form can have pushed at once
+        } else {
+            pairs = sahbvh.pairs;
+            for (NodePair &q : pairs) {
+                q.llink *= q.lcnt ? (uint32_t)sizeof(TriIsect) : (uint32_t)sizeof(NodePair);
+                q.rlink *= q.rcnt ? (uint32_t)sizeof(TriIsect) : (uint32_t)sizeof(NodePair);
+            }
         }
     }
     const std::vector<int> &slot_face = sah ? sahbvh.order : bvh.indices;
@@ -1115,7 +1134,11 @@ try {
     dev->lds_scene = scene_bytes <= 24 * 1024;
     dev->packed_queue = n < 65536;
     dev->sah = sah;
+    dev->sah_wide_on = sah && sah_wide_on;
     dev->sah_stack = sah ? sahbvh.max_stack : 0;
+    if (sah && getenv("PTAMD_VERBOSE"))
+        fprintf(stderr, "ptamd: SAH tree %zu pairs, %s form %zu records, walk stack %u entries\n", sahbvh.pairs.size(),
+                sah_wide_on ? "4-wide" : "pair", sah_wide_on ? pairs.size() / 2 : pairs.size(), sahbvh.max_stack);
     dev->walk = std::max(choose_walk(dev), 0);
     dev->queue_entries = (int)std::min<uint32_t>(std::max<uint32_t>(dev->bvh.leaves + 1, 4), 12);
     dev->has_scene = true;
@@ -1235,14 +1258,15 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.n_pairs = (int)dev->n_pairs;
     P.n_tris = (int)dev->n_tris;
     P.queue_entries = dev->queue_entries;
-    P.sah = dev->sah ? 1 : 0;
+    P.sah = dev->sah ? (dev->sah_wide_on ? 2 : 1) : 0;
     // How soon the SAH kernel's walk loop lets finished lanes shade and take their next segment.  Measured (tools/exp_pct.sh):
     // a tree that lives in the caches wants few, well-filled shading passes (C3: 40 % -> 128.8 ms; 50: 131.2, 65: 138.7);
     // a tree in HBM, whose every step waits on memory, wants its idle lanes refilled early (C4: 80 % -> 67.5 ms; 50: 72.2,
-    // 35: 77.3, 95: 81.4).
+    // 35: 77.3, 95: 81.4).  The 4-wide form's visits are fatter and fewer, which moves the big-scene optimum down
+    // (C4: 57.4 / 57.9 / 53.0 / 55.0 / 56.0 / 58.0 / 65.8 ms at 30 / 40 / 50 / 60 / 70 / 80 / 90 %; C3 stays at 40).
     {
         const size_t scene_bytes = dev->n_pairs * sizeof(NodePair) + dev->n_tris * sizeof(TriIsect);
-        P.spec_pct = dev->spec_pct >= 0 ? dev->spec_pct : (scene_bytes > ((size_t)64 << 20) ? 80 : 40);
+        P.spec_pct = dev->spec_pct >= 0 ? dev->spec_pct : (scene_bytes > ((size_t)64 << 20) ? (dev->sah_wide_on ? 50 : 80) : 40);
     }
     P.fold_bits = dev->fold_bits;
     P.deal_cap = 0; P.deal_min = dev->deal_min; P.any_tex = dev->any_tex ? 1 : 0; P.lrpt = dev->lrpt;
@@ -1317,6 +1341,7 @@ static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool 
         (void)scene_bytes;      // round 1 picked the 6-wave build for cache-resident scenes; after round 2's diet the natural
                                 // (5-wave, spill-free) build is as fast there (C3 132.9 vs 133.8 ms) and faster on C4
         const bool six = dev->sah_waves == 6;
+        if (dev->sah_wide_on) return PT_KERNEL(dev::render_kernel_sahw);
         return six ? PT_KERNEL(dev::render_kernel_sah6) : PT_KERNEL(dev::render_kernel_sah);
     }
     if (walk == 3) return PT_KERNEL(dev::render_kernel<false, true, 3>);

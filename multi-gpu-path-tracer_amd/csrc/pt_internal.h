@@ -101,6 +101,16 @@ struct SahBvh {
 };
 void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out);
 
+// The SAH tree in 4-wide form for the device (pt_walk.h, wide SAH walk): a QuadNode holds up to four child boxes, made
+// from a pair by replacing its larger inner children with their own two children.  128 B = two NodePair-sized halves:
+// floats [0..11] the boxes of children 0 and 1 (x/y/z min, max each, as in NodePair), [12..23] children 2 and 3 (second
+// half's floats [0..11]), links in the FIRST half's link words [12..15]; the second half's link words are unused.
+// A link is a BYTE offset: of a QuadNode (multiple of 128: low four bits zero), or of a leaf's first TriIsect record
+// (multiple of 48, so of 16) with the leaf's triangle count (1..15) in the low four bits.  An absent child has an inverted
+// box and is never hit.  Returns false when the tree cannot take this form (a leaf of more than 15 triangles, which the
+// builder only makes at its depth limit).  max_stack = the most entries a walk can have pushed at once.
+bool collapse_sah_quads(const SahBvh &in, std::vector<NodePair> &quads2, uint32_t &max_stack);
+
 struct TexDesc { int32_t w, h; uint32_t offset /* in floats */, pad; };
 
 } // namespace pt

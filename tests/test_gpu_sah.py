@@ -20,11 +20,13 @@ def _tracer(pt, scene, cam, W=8, H=8, spp=1, depth=1, sah=True):
     return tr, fb
 
 
-@pytest.mark.parametrize("name,n", [("box", 10_000_000), ("duck", 10_000_000)])
-def test_sah_closest_hits_equal_reference_traversal(pt, box_scene, duck_scene, gpu_device, name, n):
+@pytest.mark.parametrize("name,n,wide", [("box", 10_000_000, 1), ("duck", 10_000_000, 1), ("box", 4_000_000, 0), ("duck", 4_000_000, 0)])
+def test_sah_closest_hits_equal_reference_traversal(pt, box_scene, duck_scene, gpu_device, monkeypatch, name, n, wide):
     """SURVEY 8f-1 parity gate: identical closest-hit triangle and t as the reference-topology walk on
     1e7 random rays (origins inside the scene's bounds, every 13th direction in a coordinate plane).
-    Both walks run on the GPU; ties resolve by the reference's visit order in both."""
+    Both walks run on the GPU; ties resolve by the reference's visit order in both.  wide = 1: the tree in its 4-wide
+    device form (the default); 0: the pair form (PTAMD_SAH_WIDE=0)."""
+    monkeypatch.setenv("PTAMD_SAH_WIDE", str(wide))
     scene, cam = (box_scene, BOX_CAMERA) if name == "box" else (duck_scene, DUCK_CAMERA)
     rng = np.random.default_rng(11)
     tris = scene.triangles
@@ -50,14 +52,15 @@ def test_sah_closest_hits_equal_reference_traversal(pt, box_scene, duck_scene, g
     assert hits > n // 2
 
 
-@pytest.mark.parametrize("name,parts", [("box", 16), ("box", 64), ("duck", 16), ("duck", 4)])
-def test_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, duck_oracle, gpu_device, monkeypatch, name, parts):
+@pytest.mark.parametrize("name,parts,wide", [("box", 16, 1), ("box", 64, 1), ("duck", 16, 1), ("duck", 4, 0)])
+def test_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, duck_oracle, gpu_device, monkeypatch, name, parts, wide):
     """The SAH kernel hands its critically dear tiles to several waves (a few pixels each) from the third launch of a
     rectangle on: which wave renders a pixel must never change it.  PTAMD_SPLIT_PCT = 10 makes every launch's dearest
     tiles "critical", so the split paths run on these small frames; every frame must equal the oracle's, with the
     same counters (box / triangle tests included: per pixel the walk is the same)."""
     monkeypatch.setenv("PTAMD_SPLIT_PCT", "10")
     monkeypatch.setenv("PTAMD_SAH_SPLIT", str(parts))
+    monkeypatch.setenv("PTAMD_SAH_WIDE", str(wide))
     scene, cam, oracle = (box_scene, BOX_CAMERA, box_oracle) if name == "box" else (duck_scene, DUCK_CAMERA, duck_oracle)
     W, H, spp, depth = 200, 168, 3, 5               # 25 x 21 tiles: enough workgroups for a cost-ordered schedule
     tr, fb = _tracer(pt, scene, cam, W, H, spp, depth, sah=True)
@@ -81,9 +84,11 @@ def test_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, 
     tr.close()
 
 
+@pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("name,W,H,spp,depth", [("box", 160, 90, 8, 8), ("duck", 96, 54, 3, 8)])
-def test_sah_images_match_oracle(pt, box_scene, duck_scene, gpu_device, name, W, H, spp, depth):
+def test_sah_images_match_oracle(pt, box_scene, duck_scene, gpu_device, monkeypatch, name, W, H, spp, depth, wide):
     import os
+    monkeypatch.setenv("PTAMD_SAH_WIDE", str(wide))
     from conftest import ROOT
     g = np.load(os.path.join(ROOT, "tests", "golden", "%s_%dx%d_%dspp_%db.npz" % (name, W, H, spp, depth)))
     scene, cam = (box_scene, BOX_CAMERA) if name == "box" else (duck_scene, DUCK_CAMERA)

@@ -65,6 +65,7 @@ def one(seed):
     os.environ["PTAMD_SCHED_MIN_BLOCKS"] = str(int(rng.choice([1, 2, 64])))
     os.environ["PTAMD_SPLIT_PCT"] = str(int(rng.choice([10, 90])))
     os.environ["PTAMD_SAH_SPLIT"] = str(int(rng.choice([0, 4, 16, 64])))
+    os.environ["PTAMD_SAH_WIDE"] = str(int(rng.choice([0, 1, 1])))          # the SAH tree's device form: pairs or 4-wide nodes
     fb = pt.Framebuffer(pt.Resolution(W, H))
     tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, pt.CameraConfig(cam[0], cam[1], cam[2], cam[3]),
                              legacyMaterials=legacy, spheres=spheres)

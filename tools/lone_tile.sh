@@ -29,7 +29,7 @@ assert fn(tr._h, buf.ctypes.data, buf.size) == 0
 a = buf.reshape(-1, 4).copy()
 tiles_x = (W + 7) // 8
 for k in np.argsort(-a[:, 3].astype(np.int64))[:n_top]:
-    tile, cost = int(a[k, 2]), int(a[k, 3])
+    tile, cost = int(a[k, 2]) & 0x7fffffff, int(a[k, 3])
     in_frame_ms = (int(a[k, 1]) - int(a[k, 0])) / 1e5
     tx, ty = tile % tiles_x, tile // tiles_x
     # a full-frame task starts at (0, 0), so tile (tx, ty) of the frame is the 8x8 task at (8 tx, 8 ty)
