@@ -1,0 +1,177 @@
+// CPU check of the 4-wide device form of the opt-in SAH tree (pt_bvh.cpp collapse_sah_quads) -- test infrastructure,
+// built and run by tests/test_host_logic.py with plain g++ against the product's host sources.
+//
+//   quad_collapse_check <n_triangles> <seed>
+//
+// 1. structure: every QuadNode is reachable exactly once from the root, every leaf-order slot is covered exactly once,
+//    links are well-formed (inner: multiple of 128 inside the array; leaf: multiple of 48 | count 1..15), absent children
+//    have the never-entered box, and no walk order can push more entries than the reported bound;
+// 2. the walk of pt_walk.h (sahw_node_step / sahw_tri_step: nearest child first, the others pushed as link words),
+//    restated here on the host, finds the brute-force closest hit for random rays without exceeding that bound.
+// Exit code 0 = all good; prints one summary line.
+#include "pt_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <random>
+#include <vector>
+
+using namespace pt;
+
+namespace {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+struct Quad {
+    const float *box[4];
+    uint32_t link[4];
+};
+
+Quad quad_at(const std::vector<NodePair> &q, uint32_t qi)
+{
+    const NodePair &h0 = q[2 * (size_t)qi], &h1 = q[2 * (size_t)qi + 1];
+    Quad r;
+    r.box[0] = &h0.lxmin; r.box[1] = &h0.lxmin + 6; r.box[2] = &h1.lxmin; r.box[3] = &h1.lxmin + 6;
+    r.link[0] = h0.llink; r.link[1] = h0.lcnt; r.link[2] = h0.rlink; r.link[3] = h0.rcnt;
+    return r;
+}
+
+bool absent(const float *b) { return !(b[0] < INFINITY); }
+
+// plain Moller-Trumbore on raw vertices (the device's exact arithmetic is not the subject here)
+bool hit_triangle(const float *p, const float *o, const float *d, float &t)
+{
+    float e1[3], e2[3], h[3], s[3], q[3];
+    for (int k = 0; k < 3; k++) { e1[k] = p[3 + k] - p[k]; e2[k] = p[6 + k] - p[k]; }
+    h[0] = d[1] * e2[2] - d[2] * e2[1]; h[1] = d[2] * e2[0] - d[0] * e2[2]; h[2] = d[0] * e2[1] - d[1] * e2[0];
+    const float a = e1[0] * h[0] + e1[1] * h[1] + e1[2] * h[2];
+    if (std::fabs(a) < 1e-12f) return false;
+    const float f = 1.0f / a;
+    for (int k = 0; k < 3; k++) s[k] = o[k] - p[k];
+    const float u = f * (s[0] * h[0] + s[1] * h[1] + s[2] * h[2]);
+    if (u < 0 || u > 1) return false;
+    q[0] = s[1] * e1[2] - s[2] * e1[1]; q[1] = s[2] * e1[0] - s[0] * e1[2]; q[2] = s[0] * e1[1] - s[1] * e1[0];
+    const float v = f * (d[0] * q[0] + d[1] * q[1] + d[2] * q[2]);
+    if (v < 0 || u + v > 1) return false;
+    t = f * (e2[0] * q[0] + e2[1] * q[1] + e2[2] * q[2]);
+    return t > 0.001f;
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    const size_t n = argc > 1 ? (size_t)atol(argv[1]) : 3000;
+    const unsigned seed = argc > 2 ? (unsigned)atol(argv[2]) : 5u;
+    std::mt19937 rng(seed);
+    std::uniform_real_distribution<float> U(-10, 10), S(-0.5, 0.5), D(-1, 1);
+    std::vector<float> pos(9 * n);
+    for (size_t i = 0; i < n; i++) {
+        const float c[3] = {U(rng), U(rng), U(rng)};
+        for (int v = 0; v < 3; v++) for (int k = 0; k < 3; k++) pos[9 * i + 3 * v + k] = c[k] + S(rng);
+    }
+    SahBvh b;
+    build_sah_bvh(pos.data(), n, b);
+    std::vector<NodePair> q;
+    uint32_t bound = 0;
+    if (!collapse_sah_quads(b, q, bound)) { printf("collapse refused the tree\n"); return 1; }
+    const size_t nq = q.size() / 2;
+
+    // 1. structure
+    std::vector<int> slot_seen(n, 0), quad_seen(nq, 0);
+    struct Item { uint32_t link, pushed; };
+    std::vector<Item> todo{{0u, 0u}};
+    uint32_t worst_possible = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back(); todo.pop_back();
+        if (it.link & 15u) {
+            const uint32_t off = it.link & ~15u, cnt = it.link & 15u;
+            if (off % 48u) { printf("leaf link %u is not a TriIsect offset\n", it.link); return 1; }
+            for (uint32_t k = 0; k < cnt; k++) {
+                if (off / 48u + k >= n) { printf("leaf link %u leaves the triangle array\n", it.link); return 1; }
+                slot_seen[off / 48u + k]++;
+            }
+            continue;
+        }
+        if (it.link % 128u || it.link / 128u >= nq) { printf("inner link %u is not a QuadNode offset\n", it.link); return 1; }
+        const uint32_t qi = it.link / 128u;
+        quad_seen[qi]++;
+        const Quad Q = quad_at(q, qi);
+        int real = 0;
+        for (int i = 0; i < 4; i++) {
+            if (absent(Q.box[i])) {
+                for (int k = 0; k < 6; k++) if (Q.box[i][k] != INFINITY) { printf("absent child with a finite plane\n"); return 1; }
+                continue;
+            }
+            if (!(Q.box[i][0] <= Q.box[i][1])) { printf("inverted box that the slab test would accept\n"); return 1; }
+            real++;
+        }
+        const uint32_t pushed = it.pushed + (uint32_t)std::max(real - 1, 0);
+        worst_possible = std::max(worst_possible, pushed);
+        for (int i = 0; i < 4; i++) if (!absent(Q.box[i])) todo.push_back({Q.link[i], pushed});
+    }
+    for (size_t i = 0; i < n; i++) if (slot_seen[i] != 1) { printf("slot %zu covered %d times\n", i, slot_seen[i]); return 1; }
+    for (size_t i = 0; i < nq; i++) if (quad_seen[i] != 1) { printf("quad %zu reached %d times\n", i, quad_seen[i]); return 1; }
+    if (worst_possible + 1 != bound) { printf("stack bound %u, but a walk can hold %u + 1\n", bound, worst_possible); return 1; }
+
+    // 2. the walk against brute force
+    const int rays = n <= 20000 ? 20000 : 2000;
+    uint32_t deepest = 0;
+    double visits = 0;
+    std::vector<uint32_t> stack(bound + 1);
+    for (int r = 0; r < rays; r++) {
+        const float o[3] = {U(rng), U(rng), U(rng)}, d[3] = {D(rng), D(rng), D(rng)};
+        const float inv[3] = {1 / d[0], 1 / d[1], 1 / d[2]};
+        float t_brute = std::numeric_limits<float>::max();
+        int best_brute = -1;
+        for (size_t i = 0; i < n; i++) {
+            float t;
+            if (hit_triangle(&pos[9 * (size_t)b.order[i]], o, d, t) && t < t_brute) { t_brute = t; best_brute = (int)i; }
+        }
+        uint32_t pair = 0, k0 = 0, n0 = 0;
+        int sp = 0, best = -1;
+        float tbest = std::numeric_limits<float>::max();
+        auto take = [&](uint32_t x) { if (x & 15u) { k0 = x & ~15u; n0 = x & 15u; } else pair = x; };
+        auto pop = [&]() { if (sp > 0) take(stack[--sp]); };
+        while (n0 != 0 || pair != kNone) {
+            if (n0 != 0) {
+                const uint32_t s = k0 / 48u;
+                float t;
+                if (hit_triangle(&pos[9 * (size_t)b.order[s]], o, d, t) && t < tbest) { tbest = t; best = (int)s; }
+                k0 += 48u; n0--;
+                if (n0 == 0 && pair == kNone) pop();
+                continue;
+            }
+            visits++;
+            const Quad Q = quad_at(q, pair / 128u);
+            float key[4];
+            uint32_t link[4];
+            for (int i = 0; i < 4; i++) {
+                const float *f = Q.box[i];
+                const float t1 = (f[0] - o[0]) * inv[0], t2 = (f[1] - o[0]) * inv[0], t3 = (f[2] - o[1]) * inv[1], t4 = (f[3] - o[1]) * inv[1];
+                const float t5 = (f[4] - o[2]) * inv[2], t6 = (f[5] - o[2]) * inv[2];
+                const float tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+                const float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+                key[i] = ((tf >= fmaxf(tn, 0.0f)) && (tn <= tbest)) ? tn : INFINITY;
+                link[i] = Q.link[i];
+            }
+            for (int j = 1; j < 4; j++) if (key[j] < key[0]) { std::swap(key[0], key[j]); std::swap(link[0], link[j]); }
+            pair = kNone;
+            for (int j = 3; j >= 1; j--) {
+                if (!(key[j] < INFINITY)) continue;
+                if ((uint32_t)sp >= bound) { printf("walk pushed past the bound (%u entries)\n", bound); return 1; }
+                stack[sp++] = link[j];
+            }
+            deepest = std::max(deepest, (uint32_t)sp);
+            if (key[0] < INFINITY) take(link[0]); else pop();
+        }
+        const bool same = best == best_brute || (best >= 0 && best_brute >= 0 && std::fabs(tbest - t_brute) <= 1e-6f * std::fabs(t_brute));
+        if (!same) { printf("ray %d: walk found slot %d (t %g), brute force %d (t %g)\n", r, best, tbest, best_brute, t_brute); return 1; }
+    }
+    printf("ok: %zu triangles, %zu pairs -> %zu quads, stack bound %u (pair form %u), deepest in %d rays %u, %.1f visits per ray\n",
+           n, b.pairs.size(), nq, bound, b.max_stack, rays, deepest, visits / rays);
+    return 0;
+}

@@ -576,6 +576,23 @@ def test_sah_tree_invariants_and_determinism(pt, duck_scene):
         assert (covered == 1).all() and (seen_pairs == 1).all()
 
 
+def test_sah_tree_four_wide_device_form(tmp_path):
+    """The 4-wide device form of the SAH tree (collapse_sah_quads, what the default SAH kernel walks): built by plain g++
+    from the product's host sources, checked on the host -- every node reachable once, every leaf slot covered once,
+    well-formed links, absent children that the slab test can never accept (an inverted box of infinities WOULD be
+    accepted), the stack bound matching the worst walk order, and the walk itself (restated in the checker) finding
+    the brute-force closest hit within that bound.  The GPU suite checks the real walk bit for bit."""
+    import subprocess
+    csrc = os.path.join(ROOT, "multi-gpu-path-tracer_amd", "csrc")
+    exe = str(tmp_path / "quad_collapse_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", csrc, "-I", os.path.join(ROOT, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "native", "quad_collapse_check.cpp"),
+                    os.path.join(csrc, "pt_bvh.cpp"), os.path.join(csrc, "pt_common.cpp"), "-pthread"], check=True)
+    for n, seed in ((1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (9, 6), (17, 7), (37, 8), (500, 9), (3000, 10), (40000, 11)):
+        r = subprocess.run([exe, str(n), str(seed)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.startswith("ok:"), (n, seed, r.stdout, r.stderr)
+
+
 def test_missing_native_library_fails_loudly(pt, monkeypatch):
     """No silent fallback: without libptamd.so the binding raises at first use."""
     monkeypatch.setattr(pt.capi, "_lib", None)
