@@ -244,9 +244,9 @@ def main():
     ap.add_argument("--width", type=int, default=0, help="diagnostic: override the config's width")
     ap.add_argument("--height", type=int, default=0, help="diagnostic: override the config's height")
     ap.add_argument("--spp", type=int, default=0, help="diagnostic: override the config's samples per pixel")
-    ap.add_argument("--walk", type=int, default=0, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--walk", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="diagnostic: pt_set_traversal_mode (0 auto, 1 per-lane, 2 wave-uniform mask, 3 wave-uniform stack, "
-                         "4 mask walk with dealt sparse leaves)")
+                         "4 mask walk with dealt sparse leaves, 5 stack walk with dealt sparse leaves)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on a box with ONE GPU: every rank uses cuda:0 and the exchange runs "
                          "over gloo (RCCL needs one GPU per rank); checks the N > 1 code path, not its speed")

@@ -212,6 +212,101 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
     }
 }
 
+// The stack walk with dealt sparse leaves (kWalk 5, traverse_uniform_stack_dealt): render_kernel_dealt's frame -- persistent
+// waves, convergent trips, issue priority, split tiles -- around the walk for trees of up to 4 096 inner nodes (the duck).
+#ifndef PT_DEAL_STACK_WAVES
+#define PT_DEAL_STACK_WAVES 5
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_STACK_WAVES, PT_DEAL_STACK_WAVES))) void render_kernel_dealt_stack(RenderParams P)
+{
+    extern __shared__ float4 lds_raw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
+    const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
+    const DealView32 D = deal_carve32(P, V.end, tid);
+    uint32_t *stack = LL.stack + tid;
+    // Split tiles (see render_sah_body): here a trip's cost is mostly the wave's (box walk, shading), so a part of 16
+    // pixels still costs ~0.65 of the tile per trip -- worth it only when the tile's chain bounds the launch, i.e. for
+    // a rank's share of a multi-GPU frame, where there are fewer tiles than wave slots (split_count_kernel decides).
+    const uint32_t parts = (uint32_t)P.split_parts;
+    uint32_t n_split = 0, n_slots_all = 0;
+    {
+        KernargParams &K = *fresh_kernarg();
+        if (K.n_split) n_split = K.n_split[0];
+        n_slots_all = K.n_slots + n_split * (parts - 1u);
+    }
+    // Persistent waves: the launch has as many workgroups as the device holds at once, and every WAVE takes its next tile
+    // from a counter when its own tile is done.  With one workgroup per four tiles a finished wave's slot stayed empty until
+    // its three siblings were done too (5 % of the slots of a C2 frame), and the shading tables were staged 8 100 times.
+    while (true) {
+        KernargParams &K = *fresh_kernarg();
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(K.tile_next, 1u);
+        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+        if (slot >= n_slots_all) break;                    // every wave gets here: the counter only grows
+#ifdef PT_TIMELINE
+        const uint32_t tl_start = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
+        const SlotWork sw = slot_work(K, slot, n_split, parts, lane);
+        const int tile = sw.tile;
+        int x, y, pixel_index;
+        const bool in_frame = tile_pixel(K, tile, sw.tile_lane, x, y, pixel_index) && sw.lane_on;
+        PathState L;
+        path_init(L, P, pixel_index);
+        bool alive = in_frame && P.depth > 0;
+        // wave totals in scalar registers: box / triangle tests (as in the mask walk), segments (lanes that trace in a trip)
+        // and the trip count itself, which is this tile's cost for the next launch's order
+        unsigned long long wave_box = 0, wave_tri = 0;
+        uint32_t wave_seg = 0, trips = 0;
+        // Issue priority by remaining work (P.lrpt; measured neutral): a wave that still has most of its samples
+        // ahead outranks one that is nearly done.
+        int prio_now = 0;
+        while (true) {
+            const unsigned long long alive_mask = pt_ballot(alive);
+            if (alive_mask == 0ull) break;
+            if (P.lrpt) {
+                const int s_now = __builtin_amdgcn_readlane(L.s, (int)__builtin_ctzll(alive_mask));     // a tile's pixels progress within a few %
+                const int left4 = (P.spp - s_now) * 4;
+                const int want = left4 > 3 * P.spp ? 3 : left4 > 2 * P.spp ? 2 : left4 > P.spp ? 1 : 0;
+                if (want != prio_now) {
+                    prio_now = want;
+                    if (want == 3) __builtin_amdgcn_s_setprio(3);
+                    else if (want == 2) __builtin_amdgcn_s_setprio(2);
+                    else if (want == 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+            }
+            bool trace = alive;
+            if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
+            const unsigned long long trace_mask = pt_ballot(trace);
+            if (trace_mask != 0ull) {                          // (the last trip of a wave only discovers that every pixel is done)
+                wave_seg += (uint32_t)__popcll(trace_mask);
+                trips++;
+            }
+            const Hit h = traverse_uniform_stack_dealt(P, D, lane, trace, L.ro, L.rd, 0.001f, 3.402823466e+38f, stack, kBlock, wave_box, wave_tri);
+            if (trace) shade<false, ShadeView>(L, P, V, h);
+        }
+        KernargParams &E = *fresh_kernarg();
+        if (in_frame) write_pixel(E, L.col, pixel_index);
+        L.n_paths = in_frame ? (P.depth == 0 ? (uint32_t)P.spp : (uint32_t)L.s) : 0u;      // samples started (depth 0: rays generated, untraced)
+        L.n_seg = 0;
+        flush_counters(E, L, lane, wave_box, wave_tri, wave_seg);
+        if (E.tile_cost && lane == 0) {
+            if (sw.is_part) atomicMax(&E.tile_cost[tile], trips);      // a tile's trips = those of its busiest pixel, in whichever part
+            else E.tile_cost[tile] = trips;
+        }
+#ifdef PT_TIMELINE
+        if (lane == 0 && slot < 131072u) {
+            g_timeline[4 * slot] = tl_start;
+            g_timeline[4 * slot + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            g_timeline[4 * slot + 2] = (uint32_t)tile | (sw.is_part ? 0x80000000u : 0u);
+            g_timeline[4 * slot + 3] = trips;
+        }
+#endif
+    }
+}
+
 // Cooperative kernel for reference trees with big leaves (cornell_duck: one leaf of 1603 triangles, 2 120
 // triangle tests per ray segment).  The four waves of a workgroup render the SAME 8x8 tile: each holds
 // the full path state of its 64 pixels and does the box walk and the shading redundantly (bit-identical,
@@ -754,8 +849,11 @@ static int choose_walk(const pt_device *d)
     if (d->force_walk == 0) return 0;
     if (d->force_walk == 1) return mask_ok ? 1 : -1;
     if (d->force_walk == 2) return stack_ok ? 2 : -1;
+    // stack walk with dealt sparse leaves: key = t bits | rank << 16 | slot, both in 16 bits
+    const bool deal_stack_ok = stack_ok && d->n_tris <= 65536;
     if (d->force_walk == 4) return deal_ok ? 4 : -1;
-    return deal_ok && d->deal_auto ? 4 : (mask_ok ? 1 : (stack_ok ? 2 : 0));
+    if (d->force_walk == 5) return deal_stack_ok ? 5 : -1;
+    return deal_ok && d->deal_auto ? 4 : (mask_ok ? 1 : (stack_ok ? (deal_stack_ok && d->deal_auto ? 5 : 2) : 0));
 }
 
 // `hs` != null: stream-ordered free (the schedule's last launch has finished); null: plain free after
@@ -1209,9 +1307,9 @@ try {
 pt_status pt_set_traversal_mode(pt_device *dev, int mode)
 try {
     clear_error();
-    if (!dev || mode < 0 || mode > 4) return set_error(PT_ERR_INVALID, "mode must be 0 (auto), 1 (per-lane), 2 (wave-uniform, mask), 3 (wave-uniform, stack) or 4 (mask walk with dealt leaves)");
+    if (!dev || mode < 0 || mode > 5) return set_error(PT_ERR_INVALID, "mode must be 0 (auto), 1 (per-lane), 2 (wave-uniform, mask), 3 (wave-uniform, stack), 4 (mask walk with dealt leaves) or 5 (stack walk with dealt leaves)");
     const int saved = dev->force_walk;
-    dev->force_walk = mode == 4 ? 4 : mode - 1;  // -1 auto, 0 per-lane, 1 mask, 2 stack, 4 mask + dealt leaves
+    dev->force_walk = mode >= 4 ? mode : mode - 1;  // -1 auto, 0 per-lane, 1 mask, 2 stack, 4 mask + dealt leaves, 5 stack + dealt leaves
     if (dev->has_scene) {
         int w = choose_walk(dev);
         if (w < 0) {
@@ -1239,9 +1337,11 @@ static size_t lds_bytes(const RenderParams &P, int block, bool stage)
     f4 += ((size_t)P.stack_entries * block + 3) / 4;
     f4 += ((size_t)P.queue_entries * block * P.queue_dwords + 3) / 4;
     if (P.shade_lds) f4 += (P.shade_lds == 1 ? (size_t)P.n_tris * 3 : 0) + (size_t)P.n_mats * 3 + (size_t)P.n_lights * 5;
-    if (P.deal_cap > 0)       // dev::deal_carve
+    if (P.deal_cap > 0 && P.stack_entries == 0)       // dev::deal_carve (kWalk 4: no stack)
         f4 += (size_t)P.n_tris * 3 /* onb table, stage_shade_lds */ + (size_t)P.n_tris * 3 +
               (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 2 + 15) / 16);
+    if (P.deal_cap > 0 && P.stack_entries != 0)       // dev::deal_carve32 (kWalk 5: stack walk, 32-bit items, no triangle table)
+        f4 += (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 4 + 15) / 16);
     return f4 * 16;
 }
 
@@ -1347,8 +1447,9 @@ static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool 
     if (walk == 3) return PT_KERNEL(dev::render_kernel<false, true, 3>);
     if (walk == 1) return PT_KERNEL(dev::render_kernel<false, true, 1>);
     if (walk == 4) return dev->deal_min > 64 ? PT_KERNEL(dev::render_kernel_dealt<false>) : PT_KERNEL(dev::render_kernel_dealt<true>);
+    if (walk == 5 && !coop) return PT_KERNEL(dev::render_kernel_dealt_stack);
     if (coop) return PT_KERNEL(dev::render_kernel_coop);
-    if (walk == 2) return PT_KERNEL(dev::render_kernel<false, true, 2>);
+    if (walk == 2 || walk == 5) return PT_KERNEL(dev::render_kernel<false, true, 2>);
     if (dev->legacy_on) return PT_KERNEL(dev::render_kernel<false, false, 0, true>);
     if (stage) return packed ? PT_KERNEL(dev::render_kernel<true, true, 0>) : PT_KERNEL(dev::render_kernel<true, false, 0>);
     return packed ? PT_KERNEL(dev::render_kernel<false, true, 0>) : PT_KERNEL(dev::render_kernel<false, false, 0>);
@@ -1391,15 +1492,17 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     const bool stage = dev->lds_scene && walk == 0 && !dev->legacy_on, packed = dev->packed_queue && !dev->legacy_on;
     if (walk != 0) P.queue_entries = 0;
     if (walk == 1 || walk == 4) P.stack_entries = 0;
-    P.deal_cap = walk == 4 ? dev->deal_cap : 0;
+    P.deal_cap = (walk == 4 || walk == 5) ? dev->deal_cap : 0;
     // big leaves + stack walk: four waves per tile, each testing a quarter of every leaf (render_kernel_coop)
     // It pays when the launch is small for the machine (a rank's share of a multi-GPU frame): measured on
     // the duck, 1/6 of a 1080p frame and less gains (1/8: 1.85 -> 1.09 s), 1/4 and more loses (whole frame
     // 5.3 -> 7.1 s) -- the redundant box walks and the two barriers per trip cost throughput.
-    const bool coop = walk == 2 && !dev->legacy_on &&
-                      (dev->coop_mode == 1 || (dev->coop_mode < 0 && dev->bvh.max_leaf >= 64 &&
+    // (With the dealt stack walk, kWalk 5, persistent waves and split tiles do the same job better -- an eighth of the duck
+    // frame 1.09 s against 1.18 s -- so there the cooperative kernel runs only when it is asked for.)
+    const bool coop = (walk == 2 || walk == 5) && !dev->legacy_on &&
+                      (dev->coop_mode == 1 || (walk == 2 && dev->coop_mode < 0 && dev->bvh.max_leaf >= 64 &&
                                                tiles * dev::kWavesPerBlock <= 3ll * dev->max_waves));
-    if (coop) { blocks = (unsigned)tiles; P.queue_entries = 10; P.queue_dwords = 1; }   // LDS per thread: 2 x (float4 partial hit + visit rank)
+    if (coop) { blocks = (unsigned)tiles; P.queue_entries = 10; P.queue_dwords = 1; P.deal_cap = 0; }   // LDS per thread: 2 x (float4 partial hit + visit rank)
     const size_t lds = lds_bytes(P, dev::kBlock, stage);
     const KernelChoice choice = pick_kernel(dev, walk, coop, stage, packed);
     const RenderKernel kern = choice.fn;
@@ -1407,12 +1510,12 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         const pt_status st = ensure_lds(dev, (const void *)kern, lds);
         if (st != PT_OK) return st;
     }
-    const bool persistent = walk == 4 || (walk == 3 && dev->sah_persistent);
+    const bool persistent = walk == 4 || (walk == 5 && !coop) || (walk == 3 && dev->sah_persistent);
     hipStream_t hs = (hipStream_t)stream;
     pt_device::LaunchEvents ev;
     TileSchedule *sched = nullptr;
     P.tile_order = nullptr; P.tile_cost = nullptr; P.n_split = nullptr; P.split_parts = 16;
-    const int split_parts = walk == 4 ? dev->deal_split : (walk == 3 && dev->sah_persistent) ? dev->sah_split : 0;
+    const int split_parts = (walk == 4 || (walk == 5 && !coop)) ? dev->deal_split : (walk == 3 && dev->sah_persistent) ? dev->sah_split : 0;
     const bool split = split_parts > 0;
     // An error between here and the bookkeeping at the end gives the event pair back and releases the schedule.
     auto fail = [&](pt_status st) {

@@ -211,6 +211,23 @@ __device__ __forceinline__ DealView deal_carve(const RenderParams &P, float4 *ld
     return D;
 }
 
+// LDS of the stack walk with dealt leaves (kWalk 5): per wave {64 x float4 ray_a, 64 x u64 keys, 64 x float2 ray_b,
+// deal_cap x u32 items}; the triangle table stays in memory.  Mirrored by lds_bytes() on the host.
+__device__ __forceinline__ DealView32 deal_carve32(const RenderParams &P, float4 *lds, int tid)
+{
+    DealView32 D;
+    const int wave = tid / kWave;
+    const size_t per_wave_f4 = (size_t)kWave + kWave / 2 + kWave / 2 + ((size_t)P.deal_cap * 4 + 15) / 16;
+    float4 *w = lds + (size_t)wave * per_wave_f4;
+    D.ray_a = w;
+    D.keys = reinterpret_cast<unsigned long long *>(w + kWave);
+    D.ray_b = reinterpret_cast<float2 *>(w + kWave + kWave / 2);
+    D.items = reinterpret_cast<uint32_t *>(w + kWave + kWave);
+    D.cap = P.deal_cap;
+    D.deal_min = P.deal_min;
+    return D;
+}
+
 // render, DevicePathTracer.h:73-120, with render_init (:46-55) folded in and
 // camera::ray_color (camera.h:49-83) flattened into a per-lane state machine.
 // Per-lane integrator state of camera::ray_color (camera.h:49-83) and of render's sample loop

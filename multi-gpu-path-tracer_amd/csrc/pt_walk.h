@@ -495,6 +495,153 @@ __device__ __forceinline__ Hit traverse_uniform_stack(const RenderParams &P, v3 
     return h;
 }
 
+// ---- the stack walk with DEALT sparse leaves (kWalk 5) -------------------------------------------------------------
+// traverse_uniform_stack runs a leaf's triangle loop for the whole wave as soon as one lane's ray hit the leaf's box.
+// On the duck that is fine for the one leaf of 1 603 triangles, which nearly every ray hits, and wasteful for the ~330
+// small leaves, each hit by a few lanes: the wave runs ~4 900 triangle iterations per trip of which a lane needs 2 120
+// (PMC: 56 % lane utilisation, 5.4 s per C3 frame).  As in kWalk 4, a leaf that fewer than `deal_min` lanes hit is not
+// tested in place: its (ray, triangle) pairs go on the wave's LDS list -- 32-bit items here, lane | slot << 6 -- and the
+// list is worked off 64 items at a time, a chunk whenever it fills up and the rest after the walk; triangle records come
+// from memory (the table does not fit LDS), rays and keys from LDS.  Closest hit = min over the key
+// (t bits, visit rank, slot), in place and in the list alike -- triangle.h:100's strict in-order update.
+struct DealView32 {
+    uint32_t *items;                 // this wave's item list: lane | slot << 6
+    float4 *ray_a;                   // this wave's 64 x {o.x, o.y, o.z, d.x}
+    float2 *ray_b;                   // this wave's 64 x {d.y, d.z}
+    unsigned long long *keys;        // this wave's 64 closest-hit keys: t bits << 32 | rank << 16 | slot
+    int cap;                         // item list capacity
+    int deal_min;                    // a leaf hit by at least this many lanes is tested in place
+};
+
+__device__ __forceinline__ void deal_rounds32(const RenderParams &P, const DealView32 &D, int lane, uint32_t n_items, float tmin, float tmax0)
+{
+    wave_lds_fence();
+    const float4 *tg = reinterpret_cast<const float4 *>(P.tris);
+    for (uint32_t j0 = 0; j0 < n_items; j0 += kWave) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        if (j < n_items) {
+            const uint32_t it = D.items[j];
+            const uint32_t r = it & 63u, k = it >> 6;
+            const float4 ra = D.ray_a[r];
+            const float2 rb = D.ray_b[r];
+            const float4 ta = tg[3 * (size_t)k], tb = tg[3 * (size_t)k + 1];
+            const float2 tc = reinterpret_cast<const float2 *>(tg + 3 * (size_t)k + 2)[0];
+            float t, u, v;
+            const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x),
+                                    mk3(ra.x, ra.y, ra.z), mk3(ra.w, rb.x, rb.y), t, u, v);
+            if (ok & (t < tmax0) & (t > tmin))           // triangle.h:98 with the segment's initial interval
+                atomicMin(&D.keys[r], ((unsigned long long)__float_as_uint(t) << 32) | ((unsigned long long)__float_as_uint(tc.y) << 16) | k);
+        }
+    }
+    wave_lds_fence();
+}
+
+// Called by ALL 64 lanes of the wave (lanes without a ray pass live = false), like traverse_uniform_dealt.
+__device__ __forceinline__ Hit traverse_uniform_stack_dealt(const RenderParams &P, const DealView32 &D, int lane, bool live, v3 o, v3 d, float tmin,
+                                                            float tmax0, uint32_t *stack, int stride, unsigned long long &n_box,
+                                                            unsigned long long &n_tri)
+{
+    unsigned long long best = ~0ull;
+    const v3 inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
+    const ConstF4 nodes = as_constant(P.nodes);
+    const ConstF4 tris = as_constant(P.tris);
+    D.ray_a[lane] = make_float4(o.x, o.y, o.z, d.x);
+    D.ray_b[lane] = make_float2(d.y, d.z);
+    D.keys[lane] = ~0ull;
+    uint32_t n_items = 0;                                // wave-uniform
+    bool any_items = false;                              // wave-uniform
+    uint32_t next = 0;
+    int sp = 0;
+    bool walking = live;
+    const int n_pairs = P.n_pairs;
+    for (int p = 0; p < n_pairs; p++) {
+        const bool on = walking && next == (uint32_t)p;
+        const unsigned long long on_mask = pt_ballot(on);
+        if (on_mask == 0ull) {
+            if (pt_ballot(walking) == 0ull) break;        // every lane of the wave is done
+            continue;
+        }
+        const float4 a = nodes[4 * p], b = nodes[4 * p + 1], c = nodes[4 * p + 2], lf = nodes[4 * p + 3];
+        const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
+        const uint32_t rlink = __float_as_uint(lf.z), rcnt = __float_as_uint(lf.w);
+        const bool hl = on && box_hit(a.x, a.y, a.z, a.w, b.x, b.y, o, inv);
+        const bool hr = on && box_hit(b.z, b.w, c.x, c.y, c.z, c.w, o, inv);
+        n_box += 2u * (uint32_t)pt_popc(on_mask);
+        if (on) {
+            const bool tl = hl && lcnt == 0, tr = hr && rcnt == 0;
+            if (tl && tr) {
+                stack[sp * stride] = rlink;
+                sp++;
+                next = llink;
+            } else if (tl || tr) {
+                next = tl ? llink : rlink;
+            } else if (sp == 0) {
+                walking = false;
+            } else {
+                sp--;
+                next = stack[sp * stride];
+            }
+        }
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const bool hit = side ? hr : hl;
+            const uint32_t link = side ? rlink : llink, cnt = side ? rcnt : lcnt;
+            const unsigned long long hit_mask = cnt != 0 ? pt_ballot(hit) : 0ull;
+            if (hit_mask == 0ull) continue;
+            const uint32_t lanes = (uint32_t)pt_popc(hit_mask);
+            n_tri += (unsigned long long)cnt * lanes;
+            if ((int)lanes < D.deal_min) {
+                // sparse leaf: its pairs go on the list, triangle-major; a list that cannot take another triangle's pairs
+                // is worked off first (a big leaf hit by a few lanes passes through in chunks)
+                const uint32_t rank_in = __builtin_amdgcn_mbcnt_hi((uint32_t)(hit_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit_mask, 0u));
+                any_items = true;
+                uint32_t k0 = 0;
+                while (k0 < cnt) {
+                    const uint32_t room = ((uint32_t)D.cap - n_items) / lanes;
+                    if (room == 0) { deal_rounds32(P, D, lane, n_items, tmin, tmax0); n_items = 0; continue; }
+                    const uint32_t take = cnt - k0 < room ? cnt - k0 : room;
+                    if (hit) {
+                        const uint32_t pos = n_items + rank_in;
+                        for (uint32_t k = 0; k < take; k++) D.items[pos + k * lanes] = (uint32_t)lane | ((link + k0 + k) << 6);
+                    }
+                    n_items += take * lanes;
+                    k0 += take;
+                }
+            } else {
+                for (uint32_t k = link; k < link + cnt; k++) {
+                    const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
+                    const float e2z = tris.scalar(3 * k + 2, 0);
+                    const uint32_t low = (__float_as_uint(tris.scalar(3 * k + 2, 1)) << 16) | k;       // rank << 16 | slot, wave-uniform
+                    if (hit) {
+                        float t, u, v;
+                        const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, t, u, v);
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | low;
+                        if (ok & (t < tmax0) & (t > tmin) & (key < best)) best = key;     // triangle.h:98,100
+                    }
+                }
+            }
+        }
+    }
+    if (any_items) {                                     // wave-uniform
+        deal_rounds32(P, D, lane, n_items, tmin, tmax0);
+        const unsigned long long key = D.keys[lane];
+        if (key < best) best = key;
+    }
+    Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
+    if (best != ~0ull) {
+        h.t = __uint_as_float((uint32_t)(best >> 32));
+        h.slot = (int)(best & 0xffffu);
+        if (P.any_tex) {                                 // textured scene: the winner's barycentrics (same arithmetic, same bits)
+            const float4 *tg = reinterpret_cast<const float4 *>(P.tris);
+            const float4 ta = tg[3 * (size_t)h.slot], tb = tg[3 * (size_t)h.slot + 1];
+            const float e2z = reinterpret_cast<const float *>(tg + 3 * (size_t)h.slot + 2)[0];
+            float t;
+            (void)mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, t, h.u, h.v);
+        }
+    }
+    return h;
+}
+
 // Opt-in walk over the SAH tree (pt_set_bvh_mode(dev, 1); not the reference's traversal): per-lane
 // LDS stack, nearer child first, subtrees whose (epsilon-inflated) box starts beyond the closest
 // hit so far are pruned.  Triangles are tested with the same Moller-Trumbore arithmetic and the

@@ -343,7 +343,8 @@ class DevicePathTracer:
     def setTraversalMode(self, mode: int):
         """0 auto, 1 per-lane walk, 2 wave-uniform walk / path mask (<= 64 inner nodes),
         3 wave-uniform walk / LDS stack (<= 4096 inner nodes), 4 mask walk with dealt sparse leaves
-        (<= 64 inner nodes, <= 1024 triangles)."""
+        (<= 64 inner nodes, <= 1024 triangles), 5 stack walk with dealt sparse leaves (<= 4096 inner nodes,
+        <= 65536 triangles)."""
         capi.check(capi.lib().pt_set_traversal_mode(self._h, mode))
 
     # -- additions: exact work counters and kernel time (the metric's inputs)

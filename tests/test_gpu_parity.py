@@ -125,7 +125,7 @@ def test_closest_hit_matches_oracle_on_random_rays(pt, box_scene, duck_scene, bo
     tr.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("W,H,spp,depth", [(64, 64, 4, 4), (200, 120, 8, 8), (50, 34, 3, 1)])
 def test_cornell_box_image_bit_exact(pt, box_scene, box_oracle, gpu_device, W, H, spp, depth, mode):
     """Every traversal schedule (1 = per-lane two-phase walk, 2 / 3 = wave-uniform walks, 4 = mask walk with
@@ -150,10 +150,11 @@ def test_cornell_box_config1_400x400_16spp_4bounce(pt, box_scene, box_oracle, gp
     _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, 400, 400, 16, 4), ref)
 
 
-@pytest.mark.parametrize("mode,coop", [(1, -1), (3, 0), (3, 1)])
+@pytest.mark.parametrize("mode,coop", [(1, -1), (3, 0), (3, 1), (5, -1), (5, 1), (0, -1)])
 @pytest.mark.parametrize("W,H,spp,depth", [(64, 36, 2, 4), (96, 54, 3, 8)])
 def test_cornell_duck_image_bit_exact(pt, duck_scene, duck_oracle, gpu_device, W, H, spp, depth, mode, coop):
-    """Per-lane walk, wave-uniform stack walk with one wave per tile, and the cooperative kernel (four
+    """(Mode 5: the stack walk with dealt sparse leaves, the duck's default; 0: whatever the library picks.)
+    Per-lane walk, wave-uniform stack walk with one wave per tile, and the cooperative kernel (four
     waves per tile, each testing a quarter of every leaf, closest hits merged by the reference's visit
     order): bytes and all counters equal the oracle's."""
     ref = duck_oracle.render(DUCK_CAMERA, W, H, spp, depth, threads=8)
@@ -195,7 +196,7 @@ def test_edge_cases(pt, box_scene, box_oracle, gpu_device):
     assert e.value.status == 3
 
 
-@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("mode", [1, 3, 5])
 def test_synthetic_terrain_bit_exact(pt, ob, gpu_device, mode):
     """BASELINE.json configs[3] in miniature: the deterministic terrain generator at grid 48
     (4610 triangles, leaves of hundreds of triangles, traversal stack 10+ deep) against the oracle,
@@ -247,7 +248,7 @@ def _textured_scene(pt):
     return np.array(tris, pt.capi.TRIANGLE_DTYPE), mats, [tex0, tex1]
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
 def test_textures_emissive_texture_and_inheritance_quirk(pt, ob, gpu_device, mode):
     tris, mats, texs = _textured_scene(pt)
     scene = pt.HostScene.from_arrays(tris, mats, texs)
@@ -271,7 +272,7 @@ def test_depth_zero_counts_camera_rays_and_renders_black(pt, box_scene, box_orac
     black (camera.h:49-83 returns (0,0,0)).  Found by tools/fuzz_parity.py: the kernels used to report 0 paths."""
     ref = box_oracle.render(BOX_CAMERA, 24, 16, 3, 0)
     assert ref[2]["paths"] == 24 * 16 * 3 and ref[2]["segments"] == 0 and not ref[0].any()
-    for mode in (0, 1, 2, 4):
+    for mode in (0, 1, 2, 4, 5):
         _assert_same(_render_gpu(pt, box_scene, BOX_CAMERA, 24, 16, 3, 0, mode=mode), ref)
 
 
@@ -318,7 +319,7 @@ def test_random_scenes_bit_exact_in_every_walk(pt, ob, gpu_device, seed):
     W, H, spp, depth = 40, 24, 3, 6
     ref = osc.render(cam, W, H, spp, depth, threads=8)
     info = pt.host_bvh_build(tris)[0]
-    modes = [1, 3] + ([2, 4] if info["nodes"] - info["leaves"] <= 64 else [])
+    modes = [1, 3, 5] + ([2, 4] if info["nodes"] - info["leaves"] <= 64 else [])
     for mode in modes:
         _assert_same(_render_gpu(pt, scene, cam, W, H, spp, depth, mode=mode, coop=0), ref)
     _assert_same(_render_gpu(pt, scene, cam, W, H, spp, depth, mode=3, coop=1), ref)      # cooperative tiles, small leaves too

@@ -64,23 +64,25 @@ def test_band_tasks_on_several_streams_equal_whole_frame(pt, duck_scene, duck_or
     tr.close()
 
 
-@pytest.mark.parametrize("parts", [2, 4, 8])
-def test_dealt_kernel_split_tiles_never_change_a_byte(pt, box_scene, box_oracle, gpu_device, monkeypatch, parts):
-    """The dealt kernel, like the SAH kernel (test_gpu_sah.py), hands the dearest tiles of a launch whose longest chain
-    bounds it to several waves of a few pixel rows each.  PTAMD_SPLIT_PCT = 10 makes that the case on this small frame;
-    every frame -- raster order, cost order, split tiles -- must equal the oracle's, counters included."""
+@pytest.mark.parametrize("name,parts", [("box", 2), ("box", 4), ("box", 8), ("duck", 4)])
+def test_dealt_kernel_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, duck_oracle, gpu_device, monkeypatch, name, parts):
+    """The dealt kernels (mask walk for the box, stack walk for the duck), like the SAH kernel (test_gpu_sah.py), hand the
+    dearest tiles of a launch whose longest chain bounds it to several waves of a few pixel rows each.
+    PTAMD_SPLIT_PCT = 10 makes that the case on this small frame; every frame -- raster order, cost order, split tiles --
+    must equal the oracle's, counters included."""
     monkeypatch.setenv("PTAMD_SPLIT_PCT", "10")
     monkeypatch.setenv("PTAMD_DEAL_SPLIT", str(parts))
-    W, H, spp, depth = 200, 168, 3, 5
+    scene, oracle, cam, kernel = (box_scene, box_oracle, BOX_CAMERA, "dealt<") if name == "box" else (duck_scene, duck_oracle, DUCK_CAMERA, "dealt_stack")
+    W, H, spp, depth = (200, 168, 3, 5) if name == "box" else (176, 160, 2, 4)
     fb = pt.Framebuffer(pt.Resolution(W, H))
-    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
-    ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, pt.CameraConfig(cam[0], cam[1]))
+    ref = oracle.render(cam, W, H, spp, depth, threads=8)
     seen = 0
     for frame in range(5):
         fb.rgb.zero_(); fb.yuv.zero_()
         tr.resetCounters()
         tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
-        assert "dealt" in tr.kernelName()
+        assert kernel in tr.kernelName()
         cnt = tr.readCounters()
         assert np.array_equal(fb.rgb_host(), ref[0]) and np.array_equal(fb.yuv_host(), ref[1]), "frame %d" % frame
         for k in ("paths", "segments", "box_tests", "tri_tests", "light_tests"):      # the reference tree: the oracle's counts

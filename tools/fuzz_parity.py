@@ -55,7 +55,7 @@ def one(seed):
     ref = osc.render(cam, W, H, spp, depth, threads=8)
     info = pt.host_bvh_build(tris)[0]
     small = info["nodes"] - info["leaves"] <= 64
-    modes = [0, 1, 3] + ([2, 4, 4, 4] if small else [])       # 4 = mask walk with dealt sparse leaves (the box's default walk)
+    modes = [0, 1, 3, 5, 5] + ([2, 4, 4, 4] if small else [])       # 4 / 5 = mask / stack walk with dealt sparse leaves (the box's and the duck's default walks)
     mode = 0 if legacy is not None else int(rng.choice(modes))
     # the dealt walk's split between dealt and in-place leaves, and its list capacity, are read at pt_device_create
     os.environ["PTAMD_DEAL_MIN"] = str(int(rng.choice([0, 8, 24, 48, 56, 65])))
