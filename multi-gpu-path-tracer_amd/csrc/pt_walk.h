@@ -608,16 +608,28 @@ __device__ __forceinline__ Hit traverse_uniform_stack_dealt(const RenderParams &
                     k0 += take;
                 }
             } else {
-                for (uint32_t k = link; k < link + cnt; k++) {
+                // two triangles per iteration: both records are requested before either is used, so the pair costs one
+                // scalar-cache round trip and one pass through the loop's control instead of two
+                auto test = [&](float4 ta, float4 tb, float e2z, uint32_t low) {
+                    float t, u, v;
+                    const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, t, u, v);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | low;
+                    if (ok & (t < tmax0) & (t > tmin) & (key < best)) best = key;     // triangle.h:98,100
+                };
+                uint32_t k = link;
+                const uint32_t k_end = link + cnt;
+                for (; k + 1 < k_end; k += 2) {
+                    const float4 ta = tris[3 * k], tb = tris[3 * k + 1], ua = tris[3 * k + 3], ub = tris[3 * k + 4];
+                    const float te = tris.scalar(3 * k + 2, 0), ue = tris.scalar(3 * k + 5, 0);
+                    const uint32_t tl = (__float_as_uint(tris.scalar(3 * k + 2, 1)) << 16) | k;       // rank << 16 | slot, wave-uniform
+                    const uint32_t ul = (__float_as_uint(tris.scalar(3 * k + 5, 1)) << 16) | (k + 1);
+                    if (hit) { test(ta, tb, te, tl); test(ua, ub, ue, ul); }
+                }
+                if (k < k_end) {
                     const float4 ta = tris[3 * k], tb = tris[3 * k + 1];
-                    const float e2z = tris.scalar(3 * k + 2, 0);
-                    const uint32_t low = (__float_as_uint(tris.scalar(3 * k + 2, 1)) << 16) | k;       // rank << 16 | slot, wave-uniform
-                    if (hit) {
-                        float t, u, v;
-                        const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, e2z), o, d, t, u, v);
-                        const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | low;
-                        if (ok & (t < tmax0) & (t > tmin) & (key < best)) best = key;     // triangle.h:98,100
-                    }
+                    const float te = tris.scalar(3 * k + 2, 0);
+                    const uint32_t tl = (__float_as_uint(tris.scalar(3 * k + 2, 1)) << 16) | k;
+                    if (hit) test(ta, tb, te, tl);
                 }
             }
         }
