@@ -149,7 +149,8 @@ PT_API pt_status pt_set_tile_schedule(pt_device *dev, int mode);
  * scene), 2 = wave-uniform walk with a 64-bit path mask (trees of <= 64 inner nodes),
  * 3 = wave-uniform walk with a per-lane LDS stack (<= 4096 inner nodes), 4 = the mask walk with the
  * triangle tests of sparsely hit leaves dealt evenly over the wave's 64 lanes through LDS (<= 64 inner
- * nodes and <= 1024 triangles).                                                           */
+ * nodes and <= 1024 triangles), 5 = the stack walk with the same dealing (<= 4096 inner nodes and
+ * <= 65536 triangles).                                                                     */
 PT_API pt_status pt_set_traversal_mode(pt_device *dev, int mode);
 /* renderTaskAsync(RenderTask&, cudaStream_t), DevicePathTracer.h:194-214: no-op when
  * task->width == 0; asynchronous on `stream`; camera by value as at :210.               */
