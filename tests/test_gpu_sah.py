@@ -54,7 +54,7 @@ def test_sah_closest_hits_equal_reference_traversal(pt, box_scene, duck_scene, g
 
 @pytest.mark.parametrize("name,parts,wide", [("box", 16, 1), ("box", 64, 1), ("duck", 16, 1), ("duck", 4, 0)])
 def test_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, duck_oracle, gpu_device, monkeypatch, name, parts, wide):
-    """The SAH kernel hands its critically dear tiles to several waves (a few pixels each) from the third launch of a
+    """The SAH kernel hands its critically dear tiles to several waves (a few pixels each) from the second launch of a
     rectangle on: which wave renders a pixel must never change it.  PTAMD_SPLIT_PCT = 10 makes every launch's dearest
     tiles "critical", so the split paths run on these small frames; every frame must equal the oracle's, with the
     same counters (box / triangle tests included: per pixel the walk is the same)."""

@@ -60,8 +60,8 @@ summary = {
     "variant": variant,
     "source": "tools/profile_c2.sh / profile_cfg.sh: rocprofv3 --kernel-trace --stats; separate --pmc passes, one launch each; "
               "summarised by tools/make_profile_summary.py",
-    # the first launches are the warm-up frames: the very first runs in raster order, the second in cost order, and from
-    # the third on the dearest tiles may be split; avg_timed = the last `steps` launches, what bench.py's own events time
+    # the first launches are the warm-up frames: the very first runs in raster order, the later ones in cost order with
+    # the dearest tiles split where the rule asks for it; avg_timed = the last `steps` launches, what bench.py's own events time
     "kernel_trace_ms": {"launches": len(durs), "avg": sum(durs) / len(durs) / 1e6, "min": min(durs) / 1e6, "max": max(durs) / 1e6,
                         "first": durs[0] / 1e6, "avg_after_first": sum(durs[1:]) / max(len(durs) - 1, 1) / 1e6,
                         "avg_timed": sum(durs[-int(bench_line["steps"]):]) / int(bench_line["steps"]) / 1e6},
