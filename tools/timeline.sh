@@ -1,12 +1,12 @@
 #!/bin/bash
 # Diagnostic (GPU box): build with -DPT_TIMELINE, render frames of a bench.py config, dump per-tile {start, end, hw id, cost}
 # (100 MHz counter) of the last launch, in launch order, to gpurun_out/timeline_<tag>.npy, restore the normal build.
-# usage: bash tools/timeline.sh <tag> [config=c2]
+# usage: bash tools/timeline.sh <tag> [config=c2] [sah]   (c4 always uses the SAH tree)
 set -e
-cd $GRAFT_REPO_ROOT; TAG=${1:-c2}; CFG=${2:-c2}
+cd $GRAFT_REPO_ROOT; TAG=${1:-c2}; CFG=${2:-c2}; SAH=${3:-}
 cp multi-gpu-path-tracer_amd/libptamd.so /tmp/lib_keep.so
 make -C multi-gpu-path-tracer_amd/csrc -B EXTRA=-DPT_TIMELINE ../libptamd.so > /dev/null 2>&1
-python3 - $TAG $CFG <<'PY'
+python3 - $TAG $CFG $SAH <<'PY'
 import sys, importlib, ctypes as C, numpy as np
 sys.path.insert(0, ".")
 import bench
@@ -16,7 +16,7 @@ kind, W, H, spp, depth, desc = bench.CONFIGS[cfg]
 scene, camera = bench.load_scene(pt, kind)
 rc = pt.RendererConfig(samplesPerPixel=spp, recursionDepth=depth, gpuNumber=1, resolution=pt.Resolution(W, H), showTasks=False,
                        algorithmType=pt.FSFL)
-mgr = pt.RenderManager(rc, scene, pt.CameraConfig(camera[0], camera[1]), device_idx=0, band_rows=8, bvh_mode=1 if cfg == "c4" else 0)
+mgr = pt.RenderManager(rc, scene, pt.CameraConfig(camera[0], camera[1]), device_idx=0, band_rows=8, bvh_mode=1 if (cfg == "c4" or len(sys.argv) > 3) else 0)
 tr = mgr.tracer
 for _ in range(3):
     tr.resetKernelTime()
