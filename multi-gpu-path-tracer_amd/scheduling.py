@@ -409,12 +409,17 @@ class RenderManager:
             exchange.post()                       # rank 0: receives are in flight while it renders its own bands
         self.renderTasks()
         self.synchronize()
-        if self.dynamic():
-            self._begin_redeal()
         if exchange is not None:
             packed = pack_rank_bands(self.framebuffer_.rgb, self.framebuffer_.yuv, res.width, res.height,
                                      self.band_rows, self.assignment_[self.rank], self._torch)
             exchange.finish(packed, self.framebuffer_.rgb, self.framebuffer_.yuv)
+        # ORDER MATTERS on RCCL: point-to-point batches and collectives of one process group share one communicator and
+        # one stream, so every rank must enqueue them in the same order -- the frame's exchange first (rank 0's grouped
+        # receives were posted before rendering, the peers' sends are in finish()), the cost all-reduce after it.  The
+        # other order on the peers (all-reduce, then send) would leave rank 0's receive waiting for a send queued behind
+        # an all-reduce that waits for rank 0's, queued behind that receive.  tests/test_distributed_gloo.py pins it.
+        if self.dynamic():
+            self._begin_redeal()
         self.last_frame_ms = (time.perf_counter() - t0) * 1e3
 
     def getCurrentFrame(self) -> np.ndarray:

@@ -105,3 +105,99 @@ def test_single_rank_gather_is_identity(pt):
     packed = pt.pack_bands(rgb, yuv, W, H, pt.band_row_ranges(H, band, 1, 0), torch)
     pt.gather_frame(packed, W, H, band, r2, y2)
     assert torch.equal(r2, rgb) and torch.equal(y2, yuv)
+
+
+class _FakeTracer:
+    """Stands in for DevicePathTracer in the orchestration test below: "rendering" a band copies its bytes out of a
+    reference frame, a band's cost is a fixed function of its index (as the real per-tile trip counts are)."""
+
+    def __init__(self, pt, ref_rgb, ref_yuv, fb, W, H, band, costs):
+        self.pt, self.ref_rgb, self.ref_yuv, self.fb, self.W, self.H, self.band, self.costs = pt, ref_rgb, ref_yuv, fb, W, H, band, costs
+        self.last = []
+
+    def _render(self, bands):
+        ranges = self.pt.bands_to_ranges(self.H, self.band, bands)
+        self.pt.unpack_bands(self.pt.pack_bands(self.ref_rgb, self.ref_yuv, self.W, self.H, ranges, torch),
+                             self.fb.rgb, self.fb.yuv, self.W, self.H, ranges)
+        self.last = list(bands)
+
+    def renderBandsAsync(self, band_rows, world, rank, stream=None):
+        self._render(list(range(rank, (self.H + band_rows - 1) // band_rows, world)))
+
+    def renderBandListAsync(self, band_rows, bands, stream=None):
+        self._render(bands)
+
+    def synchronizeStream(self, s):
+        pass
+
+    def bandCosts(self):
+        return [self.costs[b] for b in self.last]
+
+    def close(self):
+        pass
+
+
+class _FakeFb:
+    pass
+
+
+def _order_worker(rank, world, port, W, H, band, out_dir):
+    """RenderManager.renderFrame under DSFL with every torch.distributed call of the frame logged: RCCL runs the
+    point-to-point batches and the collectives of one group on one communicator / one stream, so the SEQUENCE of calls
+    must be the same on every rank (rank 0 posted recv, all-reduce while the peers posted all-reduce, send
+    -> deadlock on the nccl backend, invisible on gloo)."""
+    sys.path.insert(0, ROOT)
+    pt = importlib.import_module(PKG)
+    sched = importlib.import_module(PKG + ".scheduling")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+    real_batch, real_allreduce = dist.batch_isend_irecv, dist.all_reduce
+
+    def batch(ops):
+        log.append("p2p")
+        return real_batch(ops)
+
+    def allreduce(*a, **k):
+        log.append("all_reduce")
+        return real_allreduce(*a, **k)
+
+    dist.batch_isend_irecv, dist.all_reduce = batch, allreduce
+    total = W * H
+    rng = np.random.default_rng(7)
+    ref_rgb = torch.from_numpy(rng.integers(0, 256, total * 3, dtype=np.uint8))
+    ref_yuv = torch.from_numpy(rng.integers(0, 256, total + 2 * (total // 4), dtype=np.uint8))
+    n_bands = (H + band - 1) // band
+    mgr = object.__new__(sched.RenderManager)              # the orchestration only: no GPU, no DevicePathTracer
+    mgr._torch = torch
+    mgr.config_ = pt.RendererConfig(samplesPerPixel=1, recursionDepth=1, gpuNumber=world, resolution=pt.Resolution(W, H),
+                                    showTasks=False, algorithmType=pt.DSFL)
+    mgr.rank, mgr.world, mgr.band_rows, mgr.streams = rank, world, band, [None]
+    fb = _FakeFb()
+    fb.rgb, fb.yuv = torch.zeros_like(ref_rgb), torch.zeros_like(ref_yuv)
+    mgr.framebuffer_ = fb
+    mgr.tracer = _FakeTracer(pt, ref_rgb, ref_yuv, fb, W, H, band, _costs(n_bands, 11))
+    mgr._make_tasks()
+    frames = []
+    for frame in range(3):
+        log.clear()
+        mgr.renderFrame()
+        frames.append(list(log))
+        if rank == 0:
+            assert torch.equal(fb.rgb, ref_rgb) and torch.equal(fb.yuv, ref_yuv), "frame %d" % frame
+            fb.rgb.zero_(); fb.yuv.zero_()
+    assert not mgr.static_ and mgr.assignment_ == pt.lpt_assignment(_costs(n_bands, 11), world)   # the dealer took over
+    mgr.reset()
+    open(os.path.join(out_dir, "order_%d.txt" % rank), "w").write(repr(frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_every_rank_enqueues_the_frames_collectives_in_the_same_order(tmp_path, world):
+    mp.spawn(_order_worker, args=(world, _free_port(), 64, 72, 8, str(tmp_path)), nprocs=world, join=True)
+    orders = [eval((tmp_path / ("order_%d.txt" % r)).read_text()) for r in range(world)]
+    for r in range(world):
+        assert orders[r] == orders[0], (r, orders[r], orders[0])
+    assert orders[0][0] == ["p2p", "all_reduce"], orders[0]      # the exchange first, the cost all-reduce after it
