@@ -255,6 +255,25 @@ def main():
                          "diagnostic line instead of the metric line")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher (`python bench.py --gpus N`): this process becomes the launcher.  It has not
+        # imported torch nor touched the GPU, and it starts the N ranks as a CHILD process (never exec: see the
+        # environment's rule on replacing a process that may have initialised the GPU), relays rank 0's JSON line and
+        # leaves with the child's exit code.  The reference is one process driving every GPU (RenderManager.h:76-112);
+        # here that process is torch.distributed.run and the per-GPU threads are ranks.
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     import torch
     import torch.distributed as dist
     pt = importlib.import_module("multi-gpu-path-tracer_amd")
@@ -262,10 +281,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node == --gpus, "
+                         "or without a launcher (bench.py then starts the ranks itself)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is mandatory, there is no CPU fallback")
     if args.rehearse:
         local_rank = 0
+    if not args.rehearse and world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks but %d visible GPUs (RCCL needs one GPU per rank; --rehearse runs the "
+                         "N-rank flow on one GPU over gloo)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -273,7 +298,6 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     kind, W, H, spp, depth, desc = CONFIGS[args.config]
     if args.width or args.height:
@@ -381,7 +405,9 @@ def main():
         # roofline of the dominant (only) kernel: one launch per rank and frame
         out = {
             "metric": "ray-segments/s", "value": seg_per_s, "unit": "ray-segments/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks": dist.get_world_size() if world > 1 else 1,
+            "backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (rehearsal on one GPU)")) if world > 1 else "none",
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "scene": kind, "width": W, "height": H, "spp": spp, "bounces": depth,

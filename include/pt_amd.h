@@ -47,10 +47,29 @@ enum {
 };
 
 /* ------------------------------------------------------------------ host data model -- */
-/* HostScene.h:28-31 Vertex */
+/* The PACKED form of HostScene.h:28-31 Vertex: 20 bytes.  NOT layout-identical to the reference's struct: its
+ * `float2 texCoords` is 8-byte aligned (CUDA's float2 is __builtin_align__(8), HIP's is alignas(8)), so the reference's
+ * Vertex is 24 bytes with texCoords at offset 16, and its Triangle (HostScene.h:41-47) is 80 bytes.  Never cast a
+ * `std::vector<Triangle>::data()` of the reference to `const pt_triangle *`: hand it over with pt_triangle_layout
+ * (pt_upload_scene_strided / pt_scene_create_strided below), which reads each field at the caller's own offset.    */
 typedef struct { float position[3]; float texCoords[2]; } pt_vertex;
-/* HostScene.h:41-47 Triangle */
+/* The PACKED form of HostScene.h:41-47 Triangle: 68 bytes. */
 typedef struct { pt_vertex v0, v1, v2; int textureIdx; int materialIdx; } pt_triangle;
+/* Where the fields of the CALLER'S triangle record are: record stride and the byte offset of every field in it
+ * (three floats per position, two per texCoords, one int each for the indices).  With the reference's headers:
+ *   { sizeof(Triangle),
+ *     { offsetof(Triangle, v0.position),  offsetof(Triangle, v1.position),  offsetof(Triangle, v2.position)  },
+ *     { offsetof(Triangle, v0.texCoords), offsetof(Triangle, v1.texCoords), offsetof(Triangle, v2.texCoords) },
+ *     offsetof(Triangle, textureIdx), offsetof(Triangle, materialIdx) }
+ * which evaluates to PT_TRIANGLE_LAYOUT_REFERENCE under nvcc and hipcc alike.                                        */
+typedef struct {
+    size_t stride;
+    size_t position[3];
+    size_t texCoords[3];
+    size_t textureIdx, materialIdx;
+} pt_triangle_layout;
+#define PT_TRIANGLE_LAYOUT_REFERENCE { 80, { 0, 24, 48 }, { 16, 40, 64 }, 72, 76 }
+#define PT_TRIANGLE_LAYOUT_PACKED    { 68, { 0, 20, 40 }, { 12, 32, 52 }, 60, 64 }
 /* HostScene.h:33-39 HostMaterial; a texture index of -1 is an empty std::optional<int>. */
 typedef struct {
     float baseColor[3];       int baseColorTextureIdx;
@@ -96,6 +115,13 @@ PT_API pt_status pt_upload_scene(pt_device *dev,
                                  const pt_material *materials, size_t n_materials,
                                  const pt_texture *textures, size_t n_textures);
 PT_API pt_status pt_upload_host_scene(pt_device *dev, const pt_host_scene *scene);
+/* reloadWorld() for a caller that keeps the reference's own `std::vector<Triangle>` (HostScene.h:41-47, 80-byte records
+ * with 8-byte-aligned float2 members): `triangles` points at n_triangles records laid out as `layout` says.  Fields
+ * are copied one by one into the packed form; padding bytes are never read.                                         */
+PT_API pt_status pt_upload_scene_strided(pt_device *dev, const void *triangles, size_t n_triangles,
+                                         const pt_triangle_layout *layout,
+                                         const pt_material *materials, size_t n_materials,
+                                         const pt_texture *textures, size_t n_textures);
 /* setFramebuffer(), DevicePathTracer.h:342-358: rgb = 3*w*h bytes, yuv = w*h + 2*(w*h/4)
  * bytes (Framebuffer.h:27-35), both device-accessible.  No RNG table is allocated: the
  * per-pixel XORWOW state of render_init (DevicePathTracer.h:46-55) is re-derived in-kernel. */
@@ -248,7 +274,8 @@ PT_API pt_status pt_fb_pack_tasks(pt_device *dev, const pt_task *tasks, int n_ta
 PT_API pt_status pt_fb_unpack_tasks(pt_device *dev, const pt_task *tasks, int n_tasks, const uint8_t *packed_device, pt_stream stream);
 /* One process driving N GPUs (RenderManager.h:76-112: a DevicePathTracer per GPU): the replacement for the reference's
  * implicit gather through CUDA managed memory (Framebuffer.h:27-35).  pt_gather_create makes one RCCL communicator per
- * device (ncclCommInitAll; librccl is loaded on demand, a single device needs none).  pt_gather_frame, called once per
+ * device (ncclCommInitAll; librccl is loaded on demand, a single device needs none; see pt_gather_transport for the
+ * fallback).  pt_gather_frame, called once per
  * frame after every render stream has been synchronised: device task_device[i] (an index into `devices`) rendered
  * tasks[i]; every device but the first packs its rectangles, ONE ncclGroupStart / ncclSend + ncclRecv per peer /
  * ncclGroupEnd moves the strings to the first device over each peer's own xGMI link, the first device scatters them
@@ -257,6 +284,10 @@ PT_API pt_status pt_fb_unpack_tasks(pt_device *dev, const pt_task *tasks, int n_
 typedef struct pt_gather pt_gather;
 PT_API pt_status pt_gather_create(pt_device *const *devices, int n_devices, pt_gather **out);
 PT_API pt_status pt_gather_destroy(pt_gather *gather);
+/* How the strings travel: "rccl", or "peer-copy (<why>)" -- the fallback when librccl cannot be loaded, ncclCommInitAll
+ * fails, PTAMD_GATHER=peer is set or one GPU is listed more than once: the same packed strings moved with one
+ * hipMemcpyPeerAsync per peer (xGMI where peers have direct access) -- or "none" for a single device.              */
+PT_API pt_status pt_gather_transport(const pt_gather *gather, char *out, size_t cap);
 PT_API pt_status pt_gather_frame(pt_gather *gather, const pt_task *tasks, const int *task_device, int n_tasks,
                                  uint8_t *rgb_host, uint8_t *yuv_host);
 
@@ -292,6 +323,14 @@ PT_API pt_status pt_scene_create(const pt_triangle *triangles, size_t n_triangle
                                  const pt_material *materials, size_t n_materials,
                                  const pt_texture *textures, size_t n_textures,
                                  pt_host_scene **out);
+/* pt_scene_create for triangle records in the caller's own layout (see pt_triangle_layout). */
+PT_API pt_status pt_scene_create_strided(const void *triangles, size_t n_triangles, const pt_triangle_layout *layout,
+                                         const pt_material *materials, size_t n_materials,
+                                         const pt_texture *textures, size_t n_textures,
+                                         pt_host_scene **out);
+/* The conversion both of the above use, on its own: n records at `triangles` in `layout` -> packed pt_triangle[n]. */
+PT_API pt_status pt_triangles_repack(const void *triangles, size_t n_triangles, const pt_triangle_layout *layout,
+                                     pt_triangle *out);
 PT_API void      pt_scene_free(pt_host_scene *scene);
 PT_API size_t    pt_scene_triangle_count(const pt_host_scene *scene);
 PT_API size_t    pt_scene_material_count(const pt_host_scene *scene);

@@ -25,6 +25,13 @@ TRIANGLE_DTYPE = np.dtype([("v0", VERTEX_DTYPE), ("v1", VERTEX_DTYPE), ("v2", VE
 MATERIAL_DTYPE = np.dtype([("baseColor", np.float32, 3), ("baseColorTextureIdx", np.int32),
                            ("emissiveFactor", np.float32, 3), ("emissiveTextureIdx", np.int32)])
 assert TRIANGLE_DTYPE.itemsize == 68 and MATERIAL_DTYPE.itemsize == 32
+# The reference's TRUE Triangle (HostScene.h:28-47 as nvcc / hipcc lay it out): float2 is 8-byte aligned, so a Vertex is
+# 24 bytes with texCoords at 16 and a Triangle 80 bytes.  TRIANGLE_DTYPE above is the C ABI's packed form.
+REFERENCE_VERTEX_DTYPE = np.dtype({"names": ["position", "texCoords"], "formats": [(np.float32, 3), (np.float32, 2)],
+                                   "offsets": [0, 16], "itemsize": 24})
+REFERENCE_TRIANGLE_DTYPE = np.dtype({"names": ["v0", "v1", "v2", "textureIdx", "materialIdx"],
+                                     "formats": [REFERENCE_VERTEX_DTYPE] * 3 + [np.int32, np.int32],
+                                     "offsets": [0, 24, 48, 72, 76], "itemsize": 80})
 # extension records (pt_set_legacy_scene)
 LEGACY_MATERIAL_DTYPE = np.dtype([("kind", np.int32), ("albedo", np.float32, 3), ("param", np.float32)])
 SPHERE_DTYPE = np.dtype([("center", np.float32, 3), ("radius", np.float32), ("materialIdx", np.int32)])
@@ -33,6 +40,24 @@ assert LEGACY_MATERIAL_DTYPE.itemsize == 20 and SPHERE_DTYPE.itemsize == 20
 
 class Texture(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("data", C.POINTER(C.c_float))]
+
+
+class TriangleLayout(C.Structure):
+    """pt_triangle_layout: stride of the caller's triangle record and the byte offset of each field in it."""
+    _fields_ = [("stride", C.c_size_t), ("position", C.c_size_t * 3), ("texCoords", C.c_size_t * 3),
+                ("textureIdx", C.c_size_t), ("materialIdx", C.c_size_t)]
+
+    @staticmethod
+    def of(dtype):
+        """The layout of a numpy structured dtype with the fields of HostScene.h:41-47 Triangle."""
+        l = TriangleLayout()
+        l.stride = dtype.itemsize
+        for i, v in enumerate(("v0", "v1", "v2")):
+            vd, voff = dtype.fields[v][0], dtype.fields[v][1]
+            l.position[i] = voff + vd.fields["position"][1]
+            l.texCoords[i] = voff + vd.fields["texCoords"][1]
+        l.textureIdx, l.materialIdx = dtype.fields["textureIdx"][1], dtype.fields["materialIdx"][1]
+        return l
 
 
 class Camera(C.Structure):
@@ -74,6 +99,9 @@ _PROTOS = {
     "pt_device_destroy": (C.c_int, [_vp]),
     "pt_upload_scene": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(Texture), C.c_size_t]),
     "pt_upload_host_scene": (C.c_int, [_vp, _vp]),
+    "pt_upload_scene_strided": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(TriangleLayout), _vp, C.c_size_t, C.POINTER(Texture), C.c_size_t]),
+    "pt_scene_create_strided": (C.c_int, [_vp, C.c_size_t, C.POINTER(TriangleLayout), _vp, C.c_size_t, C.POINTER(Texture), C.c_size_t, C.POINTER(_vp)]),
+    "pt_triangles_repack": (C.c_int, [_vp, C.c_size_t, C.POINTER(TriangleLayout), _vp]),
     "pt_bind_framebuffer": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "pt_set_thread_block_size": (C.c_int, [_vp, C.c_uint, C.c_uint]),
     "pt_set_traversal_mode": (C.c_int, [_vp, C.c_int]),
@@ -106,6 +134,7 @@ _PROTOS = {
     "pt_fb_unpack_tasks": (C.c_int, [_vp, C.POINTER(Task), C.c_int, _vp, _vp]),
     "pt_gather_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(_vp)]),
     "pt_gather_destroy": (C.c_int, [_vp]),
+    "pt_gather_transport": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "pt_gather_frame": (C.c_int, [_vp, C.POINTER(Task), C.POINTER(C.c_int), C.c_int, _vp, _vp]),
     "pt_set_tile_schedule": (C.c_int, [_vp, C.c_int]),
     "pt_set_cooperative_mode": (C.c_int, [_vp, C.c_int]),

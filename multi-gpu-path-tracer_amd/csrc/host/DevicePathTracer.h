@@ -77,8 +77,10 @@ public:
             const HostTexture &t = hostScene_.textures[i];
             texs[i] = pt_texture{t.width, t.height, reinterpret_cast<const float *>(t.data.data())};
         }
-        checkPtErrors(pt_upload_scene(dev_, reinterpret_cast<const pt_triangle *>(hostScene_.triangles.data()),
-                                      hostScene_.triangles.size(), mats.data(), mats.size(), texs.data(), texs.size()));
+        // Triangle keeps the reference's 80-byte layout (8-byte-aligned float2): fields are read at their own offsets
+        const pt_triangle_layout layout = triangleLayout();
+        checkPtErrors(pt_upload_scene_strided(dev_, hostScene_.triangles.data(), hostScene_.triangles.size(), &layout,
+                                              mats.data(), mats.size(), texs.data(), texs.size()));
     }
 
     void setFramebuffer(std::shared_ptr<Framebuffer> framebuffer)

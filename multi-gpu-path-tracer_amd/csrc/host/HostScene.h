@@ -2,6 +2,7 @@
 // filled by the C ABI's GLB / OBJ readers instead of assimp + stb_image.
 #pragma once
 
+#include <cstddef>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -12,7 +13,10 @@
 
 namespace ptamd {
 
-struct Float2 { float x = 0.0f, y = 0.0f; };
+// The reference's float2 is 8-byte aligned (CUDA: __builtin_align__(8); HIP: alignas(8)), so its Vertex is 24 bytes with
+// texCoords at offset 16 and its Triangle 80 bytes (HostScene.h:28-31, :41-47).  The mirror keeps that TRUE layout, so
+// code written against the reference's structs sees the same offsets, and goes to the C ABI through pt_triangle_layout.
+struct alignas(8) Float2 { float x = 0.0f, y = 0.0f; };
 struct Vertex { Float3 position; Float2 texCoords; };
 
 struct HostMaterial {
@@ -41,7 +45,21 @@ struct HostScene {
     std::vector<std::string> materialNames{};
 };
 
-static_assert(sizeof(Triangle) == sizeof(pt_triangle), "Triangle must mirror pt_triangle");
+static_assert(sizeof(Vertex) == 24 && offsetof(Vertex, texCoords) == 16 && sizeof(Triangle) == 80 &&
+              offsetof(Triangle, v1) == 24 && offsetof(Triangle, textureIdx) == 72,
+              "Triangle must have the reference's layout (HostScene.h:28-47 with an 8-byte-aligned float2)");
+
+// The layout record the C ABI reads a std::vector<Triangle> through (include/pt_amd.h: pt_triangle_layout).
+inline pt_triangle_layout triangleLayout()
+{
+    pt_triangle_layout l = {sizeof(Triangle),
+                            {offsetof(Triangle, v0) + offsetof(Vertex, position), offsetof(Triangle, v1) + offsetof(Vertex, position),
+                             offsetof(Triangle, v2) + offsetof(Vertex, position)},
+                            {offsetof(Triangle, v0) + offsetof(Vertex, texCoords), offsetof(Triangle, v1) + offsetof(Vertex, texCoords),
+                             offsetof(Triangle, v2) + offsetof(Vertex, texCoords)},
+                            offsetof(Triangle, textureIdx), offsetof(Triangle, materialIdx)};
+    return l;
+}
 
 class SceneLoader {
 public:
@@ -72,7 +90,6 @@ public:
         const pt_material *m = pt_scene_materials(h);
         const pt_texture *x = pt_scene_textures(h);
         s.triangles.resize(nt);
-        static_assert(sizeof(Vertex) == sizeof(pt_vertex), "Vertex must mirror pt_vertex");
         for (size_t i = 0; i < nt; i++) {
             auto cv = [](const pt_vertex &v) { return Vertex{{v.position[0], v.position[1], v.position[2]}, {v.texCoords[0], v.texCoords[1]}}; };
             s.triangles[i] = Triangle{cv(t[i].v0), cv(t[i].v1), cv(t[i].v2), t[i].textureIdx, t[i].materialIdx};

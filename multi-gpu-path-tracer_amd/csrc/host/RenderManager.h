@@ -12,8 +12,11 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <iostream>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -71,22 +74,40 @@ public:
         renderTasks_ = taskGen_.generateEqualTasks(threadCount_, taskLayout_, (int)config_.resolution.width,
                                                    (int)config_.resolution.height);
         bisectionDepth_ = (int)std::log2((double)threadCount_);
-        for (unsigned i = 0; i < config_.gpuNumber; i++) {
+        bandQueue_.build((int)config_.resolution.width, (int)config_.resolution.height);
+        queueActive_.store(config_.algorithmType == DQRB);
+        for (unsigned i = 0; i < config_.gpuNumber; i++)
             devicePathTracers_.push_back(std::make_shared<DevicePathTracer>(
                 (int)i, config_.samplesPerPixel, config_.recursionDepth, config_.threadBlockSize, hScene_, framebuffer_,
                 cameraConfig_));
+        // The gather group is made BEFORE any worker thread exists: nothing is parked on the barrier if it fails.  It
+        // only fails on a HIP error: without a usable librccl (or when ncclCommInitAll refuses) the group moves the same
+        // strings with peer copies (pt_gather_transport says which).  If even that cannot be set up, every worker copies
+        // its own rectangle to the host, as single-GPU runs do.
+        bool gatherOnWorker = config_.gpuNumber == 1;
+        if (config_.gpuNumber > 1) {
+            std::vector<pt_device *> devs;
+            for (auto &dpt : devicePathTracers_) devs.push_back(dpt->handle());
+            if (pt_gather_create(devs.data(), (int)devs.size(), &gather_) != PT_OK) {
+                std::cerr << "warning: native gather unavailable (" << pt_last_error_string()
+                          << "): every worker copies its rectangle to the host" << std::endl;
+                gather_ = nullptr;
+                gatherOnWorker = true;
+            } else {
+                char how[256] = "";
+                pt_gather_transport(gather_, how, sizeof how);
+                gatherTransport_ = how;
+                if (gatherTransport_.rfind("rccl", 0) != 0) std::cerr << "warning: frame gather uses " << gatherTransport_ << std::endl;
+            }
+        }
+        for (unsigned i = 0; i < config_.gpuNumber; i++) {
             streamThreads_.emplace_back();
             for (unsigned j = 0; j < config_.streamsPerGpu; j++) {
                 int taskIdx = (int)(i * config_.streamsPerGpu + j);
                 streamThreads_[i].push_back(std::make_shared<StreamThread>((int)i, taskIdx, devicePathTracers_[i], renderTasks_, barrier_,
-                                                                          /*gatherOnWorker=*/config_.gpuNumber == 1));
+                                                                          gatherOnWorker, &bandQueue_, &queueActive_));
                 streamThreads_[i][j]->start();
             }
-        }
-        if (config_.gpuNumber > 1) {                       // one RCCL communicator per GPU, made once per setup
-            std::vector<pt_device *> devs;
-            for (auto &dpt : devicePathTracers_) devs.push_back(dpt->handle());
-            checkPtErrors(pt_gather_create(devs.data(), (int)devs.size(), &gather_));
         }
     }
 
@@ -96,6 +117,13 @@ public:
         if (!gather_) return;
         std::vector<pt_task> tasks;
         std::vector<int> owner;
+        if (queueActive_.load()) {                         // DQRB: band b was rendered by whoever pulled it this frame
+            for (size_t b = 0; b < bandQueue_.bands.size(); b++) {
+                const RenderTask &t = bandQueue_.bands[b];
+                tasks.push_back(pt_task{t.width, t.height, t.offset_x, t.offset_y});
+                owner.push_back(bandQueue_.owner[b]);
+            }
+        } else
         for (size_t k = 0; k < renderTasks_.size(); k++) {
             const RenderTask &t = renderTasks_[k];
             tasks.push_back(pt_task{t.width, t.height, t.offset_x, t.offset_y});
@@ -149,8 +177,10 @@ public:
             setup();
             return;
         }
+        queueActive_.store(config_.algorithmType == DQRB);       // workers read it after the frame's first barrier
         if (resChanged) {
             for (auto &dpt : devicePathTracers_) dpt->setFramebuffer(framebuffer_);
+            bandQueue_.build((int)config_.resolution.width, (int)config_.resolution.height);
             renderTasks_ = taskGen_.generateEqualTasks(threadCount_, taskLayout_, (int)config_.resolution.width,
                                                        (int)config_.resolution.height);
         }
@@ -260,8 +290,11 @@ public:
         reloadWorldIfNeeded();
         if (config_.algorithmType == DSFL) adjustTasksDSFL();
         else if (config_.algorithmType == DSDL) adjustTasksDSDL();
+        else if (config_.algorithmType == DQRB) bandQueue_.beginFrame();
         barrier_.wait();     // release the workers
         barrier_.wait();     // all tasks rendered (and, with one GPU, gathered by their workers)
+        if (config_.algorithmType == DQRB && !bandQueue_.everyBandExactlyOnce())
+            throw std::runtime_error("DQRB: a band of the frame was not rendered exactly once");
         gatherFrame();       // several GPUs: one RCCL exchange to GPU 0 + one copy to the host
         if (config_.showTasks) markTasks();
     }
@@ -270,10 +303,19 @@ public:
     float imbalance() const
     {
         float sum = 0.0f, mx = 0.0f;
+        if (queueActive_.load()) {                         // DQRB: what a worker is busy = the bands it pulled
+            std::vector<float> busy(config_.gpuNumber, 0.0f);
+            for (size_t b = 0; b < bandQueue_.bands.size(); b++)
+                if (bandQueue_.owner[b] >= 0) busy[(size_t)bandQueue_.owner[b]] += (float)bandQueue_.bands[b].time;
+            for (float v : busy) { sum += v; mx = std::max(mx, v); }
+            return sum > 0.0f ? mx / (sum / (float)busy.size()) : 1.0f;
+        }
         for (const RenderTask &t : renderTasks_) { sum += (float)t.time; mx = std::max(mx, (float)t.time); }
         return sum > 0.0f ? mx / (sum / (float)renderTasks_.size()) : 1.0f;
     }
-    const std::vector<RenderTask> &tasks() const { return renderTasks_; }
+    const std::vector<RenderTask> &tasks() const { return queueActive_.load() ? bandQueue_.bands : renderTasks_; }
+    const BandQueue &bandQueue() const { return bandQueue_; }
+    const std::string &gatherTransport() const { return gatherTransport_; }
 
     // black task borders drawn into the frame (RenderManager.h:449-507)
     void markTasks()
@@ -288,7 +330,7 @@ public:
             for (int xx = x; xx <= x + bold && xx < W; xx++)
                 for (int y = std::max(y0, 0); y < std::min(y1, H); y++) framebuffer_->updatePixel(y * W + xx, 0, 0, 0);
         };
-        for (const RenderTask &t : renderTasks_) {
+        for (const RenderTask &t : tasks()) {
             if (t.offset_y != 0) hline(t.offset_x, t.offset_x + t.width, t.offset_y);
             hline(t.offset_x, t.offset_x + t.width, t.offset_y + t.height);
             if (t.offset_x != 0) vline(t.offset_y, t.offset_y + t.height, t.offset_x);
@@ -345,7 +387,7 @@ private:
         for (int yy = y; yy < y + h; yy++) for (int xx = x; xx < x + w; xx++) total += grid[(size_t)yy * gw + xx];
         const double half = total / 2.0;
         double acc = 0.0;
-        if (horizontalCut && h > 1) {
+        if (h > 1 && (horizontalCut || w <= 1)) {          // the asked-for direction, or the only one a 1-wide region has
             int cut = 1;
             for (int yy = y; yy < y + h - 1; yy++) {
                 for (int xx = x; xx < x + w; xx++) acc += grid[(size_t)yy * gw + xx];
@@ -364,8 +406,10 @@ private:
             bisect(grid, gw, x, y, cut, h, level + 1, true, out);
             bisect(grid, gw, x + cut, y, w - cut, h, level + 1, true, out);
         } else {
-            bisect(grid, gw, x, y, w, h, level + 1, !horizontalCut, out);
-            out.push_back(RenderTask{0, 0, x, y});                        // degenerate: an empty task
+            // a 1 x 1 region cannot be cut: it stays whole and the other half of this subtree is empty tasks, so that the
+            // subtree still yields its 2^(depth - level) tasks and the layout keeps threadCount_ entries
+            out.push_back(RenderTask{w, h, x, y});
+            for (int k = 1; k < (1 << (bisectionDepth_ - level)); k++) out.push_back(RenderTask{0, 0, x, y});
         }
     }
 
@@ -386,6 +430,9 @@ private:
     SceneLoader &sceneLoader_;
     int bisectionDepth_ = 0;
     pt_gather *gather_ = nullptr;
+    std::string gatherTransport_{};
+    BandQueue bandQueue_{};
+    std::atomic_bool queueActive_{false};
 };
 
 } // namespace ptamd

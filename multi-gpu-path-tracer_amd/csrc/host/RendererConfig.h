@@ -17,7 +17,12 @@ struct Resolution {
 enum SchedulingAlgorithmType {
     FSFL,   // fixed-size tasks, fixed layout
     DSFL,   // task sizes adapt frame to frame, layout fixed
-    DSDL    // layout adapts too (recursive bisection; power-of-two GPU counts)
+    DSDL,   // layout adapts too (recursive bisection; power-of-two GPU counts)
+    // Not in the reference (its three policies all fix the frame's split BEFORE the frame starts): an intra-frame queue
+    // of 64-128 full-width row bands; every (GPU, stream) worker pulls the next band the moment its stream drains
+    // (BASELINE.json configs[4] "dynamic tile load-balancer").  Balances the FIRST frame after any scene /
+    // camera / resolution change, which frame-to-frame feedback cannot.
+    DQRB
 };
 
 struct RendererConfig {

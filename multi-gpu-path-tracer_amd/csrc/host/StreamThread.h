@@ -12,6 +12,7 @@
 #include <thread>
 #include <vector>
 
+#include "BandQueue.h"
 #include "DevicePathTracer.h"
 #include "barrier.h"
 
@@ -21,10 +22,12 @@ class StreamThread {
 public:
     // gatherOnWorker: this worker copies its finished rectangle to the host itself (single GPU); otherwise the
     // RenderManager gathers all devices' rectangles in one RCCL exchange after the frame barrier.
+    // queue: the DQRB policy's band queue (nullptr or inactive = the reference's one pre-assigned task per frame).
     StreamThread(int device_idx, int task_idx, std::shared_ptr<DevicePathTracer> devicePathTracer,
-                 std::vector<RenderTask> &tasks, Barrier &barrier, bool gatherOnWorker = true)
+                 std::vector<RenderTask> &tasks, Barrier &barrier, bool gatherOnWorker = true, BandQueue *queue = nullptr,
+                 const std::atomic_bool *queueActive = nullptr)
         : deviceIdx{device_idx}, taskIdx{task_idx}, devicePathTracer{devicePathTracer}, tasks_{tasks}, barrier_{barrier},
-          gatherOnWorker_{gatherOnWorker}
+          gatherOnWorker_{gatherOnWorker}, queue_{queue}, queueActive_{queueActive}
     {
         stream = devicePathTracer->createStream();
     }
@@ -45,7 +48,18 @@ public:
         while (true) {
             barrier_.wait();                       // frame start (RenderManager::renderFrame)
             if (shouldTerminate) return;
-            if ((size_t)taskIdx < tasks_.size()) {
+            if (queue_ && queueActive_ && queueActive_->load()) {
+                // DQRB: pull bands until the frame's queue is empty; this worker's stream never idles while work is left
+                for (int b = queue_->pull(deviceIdx); b >= 0; b = queue_->pull(deviceIdx)) {
+                    RenderTask &band = queue_->bands[(size_t)b];
+                    auto start = std::chrono::high_resolution_clock::now();
+                    devicePathTracer->renderTaskAsync(band, stream);
+                    devicePathTracer->synchronizeStream(stream);
+                    auto stop = std::chrono::high_resolution_clock::now();
+                    band.time = (int)std::chrono::duration_cast<std::chrono::microseconds>(stop - start).count();   // microseconds: bands are short
+                    if (gatherOnWorker_) devicePathTracer->gatherTask(band, stream);
+                }
+            } else if ((size_t)taskIdx < tasks_.size()) {
                 RenderTask &task = tasks_[(size_t)taskIdx];
                 auto start = std::chrono::high_resolution_clock::now();
                 devicePathTracer->renderTaskAsync(task, stream);
@@ -69,6 +83,8 @@ private:
     std::vector<RenderTask> &tasks_;
     Barrier &barrier_;
     bool gatherOnWorker_ = true;
+    BandQueue *queue_ = nullptr;
+    const std::atomic_bool *queueActive_ = nullptr;
 };
 
 } // namespace ptamd

@@ -46,7 +46,7 @@ int main(int argc, char **argv)
         else if (a == "--front") { if (!parse3(next(), cameraConfig.front)) { std::cerr << "bad --front\n"; return 2; } }
         else if (a == "--algo") {
             std::string v = next();
-            config.algorithmType = v == "dsfl" ? DSFL : (v == "dsdl" ? DSDL : FSFL);
+            config.algorithmType = v == "dsfl" ? DSFL : (v == "dsdl" ? DSDL : (v == "dqrb" ? DQRB : FSFL));
         } else { std::cerr << "unknown option " << a << "\n"; return 2; }
     }
     if (cornell) { cameraConfig.lookFrom = Float3{-255.5f, 252.5f, 700.0f}; cameraConfig.front = Float3{0, 0, -1}; }
@@ -76,8 +76,8 @@ int main(int argc, char **argv)
         std::cout << "Path Tracing took: " << (long)ms << "ms" << std::endl;
         unsigned long long seg = 0;
         for (auto &dpt : manager.tracers()) seg += dpt->readCounters().segments;
-        printf("{\"frame\": %d, \"ms\": %.3f, \"segments\": %llu, \"segments_per_s\": %.4g, \"imbalance\": %.3f}\n", f, ms, seg,
-               (double)seg / (ms * 1e-3), manager.imbalance());
+        printf("{\"frame\": %d, \"ms\": %.3f, \"segments\": %llu, \"segments_per_s\": %.4g, \"imbalance\": %.3f, \"tasks\": %zu}\n", f, ms, seg,
+               (double)seg / (ms * 1e-3), manager.imbalance(), manager.tasks().size());
     }
     if (pt_write_ppm(out.c_str(), (int)manager.getCurrentFrameWidth(), (int)manager.getCurrentFrameHeight(), manager.getCurrentFrame()) != PT_OK) {
         std::cerr << pt_last_error_string() << std::endl;

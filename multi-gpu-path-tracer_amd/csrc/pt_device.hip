@@ -1251,6 +1251,15 @@ try {
                            s.materials.size(), s.textures.data(), s.textures.size());
 } PT_CATCH_ALL
 
+pt_status pt_upload_scene_strided(pt_device *dev, const void *triangles, size_t n, const pt_triangle_layout *layout,
+                                  const pt_material *mats, size_t m, const pt_texture *texs, size_t k)
+try {
+    std::vector<pt_triangle> packed(n);
+    pt_status st = pt_triangles_repack(triangles, n, layout, packed.data());
+    if (st != PT_OK) return st;
+    return pt_upload_scene(dev, packed.data(), n, mats, m, texs, k);
+} PT_CATCH_ALL
+
 pt_status pt_bind_framebuffer(pt_device *dev, int width, int height, uint8_t *rgb, uint8_t *yuv)
 try {
     clear_error();
@@ -2126,7 +2135,11 @@ std::mutex g_rccl_mu;
 
 struct pt_gather {
     std::vector<pt_device *> devs;
-    std::vector<ncclComm_t> comms;           // one per device (rank i = devs[i]); empty for a single device
+    // "rccl": grouped ncclSend / ncclRecv; "peer-copy": hipMemcpyPeerAsync of the same packed strings (librccl missing,
+    // ncclCommInitAll failed, PTAMD_GATHER=peer, or one GPU listed twice); "none": a single device
+    std::string transport = "none";
+    std::string note;                        // why the fallback was taken (empty otherwise)
+    std::vector<ncclComm_t> comms;           // one per device (rank i = devs[i]); empty unless transport == "rccl"
     std::vector<hipStream_t> streams;        // one per device
     std::vector<uint8_t *> send;             // device i's packed string (i > 0), on device i
     std::vector<uint8_t *> recv;             // where device 0 receives device i's string
@@ -2142,15 +2155,29 @@ struct pt_gather {
                                              std::to_string(__LINE__) + " '" #call "'");                    \
     } while (0)
 
+static void gather_free(pt_gather *g)
+{
+    if (!g) return;
+    for (size_t i = 0; i < g->devs.size(); i++) {
+        (void)hipSetDevice(g->devs[i]->index);
+        if (i < g->streams.size() && g->streams[i]) { (void)hipStreamSynchronize(g->streams[i]); (void)hipStreamDestroy(g->streams[i]); }
+        if (i < g->send.size()) (void)hipFree(g->send[i]);
+    }
+    if (!g->devs.empty()) { (void)hipSetDevice(g->devs[0]->index); for (uint8_t *p : g->recv) (void)hipFree(p); }
+    for (ncclComm_t c : g->comms) if (c) (void)g_rccl.CommDestroy(c);
+    delete g;
+}
+
 pt_status pt_gather_create(pt_device *const *devices, int n_devices, pt_gather **out)
 try {
     clear_error();
     if (!devices || n_devices <= 0 || !out) return set_error(PT_ERR_INVALID, "bad argument");
-    std::unique_ptr<pt_gather> g(new pt_gather());
+    std::unique_ptr<pt_gather, void (*)(pt_gather *)> g(new pt_gather(), gather_free);   // streams, buffers and communicators go with it on every error path
     std::vector<int> ids;
+    bool twice = false;
     for (int i = 0; i < n_devices; i++) {
         if (!devices[i]) return set_error(PT_ERR_INVALID, "null device");
-        for (int id : ids) if (id == devices[i]->index) return set_error(PT_ERR_INVALID, "pt_gather_create: the same GPU twice (one communicator rank per GPU)");
+        for (int id : ids) if (id == devices[i]->index) twice = true;
         ids.push_back(devices[i]->index);
         g->devs.push_back(devices[i]);
     }
@@ -2162,10 +2189,33 @@ try {
         g->streams.push_back(s);
     }
     if (n_devices > 1) {
-        std::lock_guard<std::mutex> lk(g_rccl_mu);
-        if (!g_rccl.load()) return set_error(PT_ERR_UNSUPPORTED, g_rccl.error);
-        g->comms.assign((size_t)n_devices, nullptr);
-        PT_NCCL(g_rccl.CommInitAll(g->comms.data(), n_devices, ids.data()));
+        const char *force = getenv("PTAMD_GATHER");
+        g->transport = "peer-copy";
+        if (force && std::string(force) == "peer") g->note = "PTAMD_GATHER=peer";
+        else if (twice) g->note = "one GPU is listed more than once (RCCL needs one communicator rank per GPU)";
+        else {
+            std::lock_guard<std::mutex> lk(g_rccl_mu);
+            if (!g_rccl.load()) g->note = g_rccl.error;
+            else {
+                g->comms.assign((size_t)n_devices, nullptr);
+                ncclResult_t r = g_rccl.CommInitAll(g->comms.data(), n_devices, ids.data());
+                if (r == ncclSuccess) g->transport = "rccl";
+                else {
+                    g->note = std::string("ncclCommInitAll failed: ") + g_rccl.GetErrorString(r);
+                    for (ncclComm_t &c : g->comms) if (c) { (void)g_rccl.CommDestroy(c); c = nullptr; }
+                    g->comms.clear();
+                }
+            }
+        }
+        if (g->transport == "peer-copy")                 // the copies go device to device: ask for direct access where there is any
+            for (int i = 1; i < n_devices; i++) {
+                int can = 0;
+                if (ids[(size_t)i] != ids[0] && hipDeviceCanAccessPeer(&can, ids[(size_t)i], ids[0]) == hipSuccess && can) {
+                    (void)hipSetDevice(ids[(size_t)i]);
+                    hipError_t e = hipDeviceEnablePeerAccess(ids[0], 0);
+                    if (e != hipSuccess) (void)hipGetLastError();       // already enabled is fine; without it the copy is staged by the runtime
+                }
+            }
     }
     *out = g.release();
     return PT_OK;
@@ -2174,15 +2224,16 @@ try {
 pt_status pt_gather_destroy(pt_gather *g)
 try {
     clear_error();
-    if (!g) return PT_OK;
-    for (size_t i = 0; i < g->devs.size(); i++) {
-        (void)hipSetDevice(g->devs[i]->index);
-        if (i < g->streams.size() && g->streams[i]) { (void)hipStreamSynchronize(g->streams[i]); (void)hipStreamDestroy(g->streams[i]); }
-        (void)hipFree(g->send[i]);
-    }
-    if (!g->devs.empty()) { (void)hipSetDevice(g->devs[0]->index); for (uint8_t *p : g->recv) (void)hipFree(p); }
-    for (ncclComm_t c : g->comms) if (c) (void)g_rccl.CommDestroy(c);
-    delete g;
+    gather_free(g);
+    return PT_OK;
+} PT_CATCH_ALL
+
+pt_status pt_gather_transport(const pt_gather *g, char *out, size_t cap)
+try {
+    clear_error();
+    if (!g || !out || cap == 0) return set_error(PT_ERR_INVALID, "bad argument");
+    std::string t = g->transport + (g->note.empty() ? "" : " (" + g->note + ")");
+    snprintf(out, cap, "%s", t.c_str());
     return PT_OK;
 } PT_CATCH_ALL
 
@@ -2225,14 +2276,38 @@ try {
         if (st != PT_OK) return st;
     }
     // 2. ONE grouped exchange: peer i sends its string to rank 0 over its own xGMI link, rank 0 posts the matching receives
-    if (n > 1) {
+    if (n > 1 && g->transport == "rccl") {
         PT_NCCL(g_rccl.GroupStart());
+        // inside the group an error must not return: the group would stay open and swallow every later RCCL call of the
+        // process.  Remember the first failure, close the group, report then.
+        ncclResult_t bad = ncclSuccess;
+        const char *what = "";
+        for (int i = 1; i < n && bad == ncclSuccess; i++) {
+            if (bytes[(size_t)i] == 0) continue;
+            bad = g_rccl.Send(g->send[(size_t)i], bytes[(size_t)i], ncclUint8, 0, g->comms[(size_t)i], g->streams[(size_t)i]);
+            if (bad != ncclSuccess) { what = "ncclSend"; break; }
+            bad = g_rccl.Recv(g->recv[(size_t)i], bytes[(size_t)i], ncclUint8, i, g->comms[0], g->streams[0]);
+            if (bad != ncclSuccess) what = "ncclRecv";
+        }
+        ncclResult_t end = g_rccl.GroupEnd();
+        if (bad != ncclSuccess)
+            return set_error(PT_ERR_HIP, std::string("RCCL ERROR = ") + std::to_string((int)bad) + " (" + g_rccl.GetErrorString(bad) + ") in " + what + " of pt_gather_frame (group closed)");
+        PT_NCCL(end);
+    } else if (n > 1) {
+        // peer-copy transport: the same strings, one device-to-device copy per peer on the peer's stream (xGMI where the
+        // GPUs have peer access); GPU 0's stream waits for each of them before it scatters
         for (int i = 1; i < n; i++) {
             if (bytes[(size_t)i] == 0) continue;
-            PT_NCCL(g_rccl.Send(g->send[(size_t)i], bytes[(size_t)i], ncclUint8, 0, g->comms[(size_t)i], g->streams[(size_t)i]));
-            PT_NCCL(g_rccl.Recv(g->recv[(size_t)i], bytes[(size_t)i], ncclUint8, i, g->comms[0], g->streams[0]));
+            pt_device *d = g->devs[(size_t)i];
+            PT_HIP(hipSetDevice(d->index));
+            PT_HIP(hipMemcpyPeerAsync(g->recv[(size_t)i], root->index, g->send[(size_t)i], d->index, bytes[(size_t)i], g->streams[(size_t)i]));
+            hipEvent_t ev;
+            PT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            hipError_t e = hipEventRecord(ev, g->streams[(size_t)i]);
+            if (e == hipSuccess) { (void)hipSetDevice(root->index); e = hipStreamWaitEvent(g->streams[0], ev, 0); }
+            (void)hipEventDestroy(ev);                     // destruction is deferred until the recorded work is done
+            PT_HIP(e);
         }
-        PT_NCCL(g_rccl.GroupEnd());
     }
     // 3. rank 0 scatters what it received into its framebuffer (its own rectangles are there already) and hands the
     //    whole frame to the host with ONE pair of copies

@@ -958,6 +958,38 @@ try {
     return PT_OK;
 } PT_CATCH_ALL
 
+pt_status pt_triangles_repack(const void *triangles, size_t n, const pt_triangle_layout *L, pt_triangle *out)
+try {
+    clear_error();
+    if (!L || (n && (!triangles || !out))) return set_error(PT_ERR_INVALID, "null argument");
+    auto fits = [&](size_t off, size_t bytes) { return off <= L->stride && bytes <= L->stride - off; };
+    bool ok = L->stride >= 4 && fits(L->textureIdx, 4) && fits(L->materialIdx, 4);
+    for (int v = 0; v < 3; v++) ok = ok && fits(L->position[v], 12) && fits(L->texCoords[v], 8);
+    if (!ok) return set_error(PT_ERR_INVALID, "triangle layout: a field lies outside the record stride");
+    const unsigned char *base = static_cast<const unsigned char *>(triangles);
+    for (size_t i = 0; i < n; i++) {
+        const unsigned char *rec = base + i * L->stride;
+        pt_vertex *vs[3] = {&out[i].v0, &out[i].v1, &out[i].v2};
+        for (int v = 0; v < 3; v++) {                    // memcpy: the caller's record need not be aligned for float
+            std::memcpy(vs[v]->position, rec + L->position[v], 12);
+            std::memcpy(vs[v]->texCoords, rec + L->texCoords[v], 8);
+        }
+        std::memcpy(&out[i].textureIdx, rec + L->textureIdx, 4);
+        std::memcpy(&out[i].materialIdx, rec + L->materialIdx, 4);
+    }
+    return PT_OK;
+} PT_CATCH_ALL
+
+pt_status pt_scene_create_strided(const void *triangles, size_t n_triangles, const pt_triangle_layout *layout,
+                                  const pt_material *materials, size_t n_materials,
+                                  const pt_texture *textures, size_t n_textures, pt_host_scene **out)
+try {
+    std::vector<pt_triangle> packed(n_triangles);
+    pt_status st = pt_triangles_repack(triangles, n_triangles, layout, packed.data());
+    if (st != PT_OK) return st;
+    return pt_scene_create(packed.data(), n_triangles, materials, n_materials, textures, n_textures, out);
+} PT_CATCH_ALL
+
 void pt_scene_free(pt_host_scene *scene) { delete scene; }
 size_t pt_scene_triangle_count(const pt_host_scene *s) { return s ? s->impl.triangles.size() : 0; }
 size_t pt_scene_material_count(const pt_host_scene *s) { return s ? s->impl.materials.size() : 0; }

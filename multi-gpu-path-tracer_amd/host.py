@@ -46,7 +46,10 @@ class HostScene:
 
     @staticmethod
     def from_arrays(triangles: np.ndarray, materials: np.ndarray, textures: Optional[List[np.ndarray]] = None):
-        tris = np.ascontiguousarray(triangles, dtype=capi.TRIANGLE_DTYPE)
+        # any record layout with the fields of HostScene.h:41-47 (e.g. capi.REFERENCE_TRIANGLE_DTYPE, the reference's true
+        # 80-byte Triangle) goes through the strided entry point, field by field; the packed form is taken as it is
+        strided = getattr(triangles, "dtype", None) is not None and triangles.dtype.names and triangles.dtype != capi.TRIANGLE_DTYPE
+        tris = np.ascontiguousarray(triangles) if strided else np.ascontiguousarray(triangles, dtype=capi.TRIANGLE_DTYPE)
         mats = np.ascontiguousarray(materials, dtype=capi.MATERIAL_DTYPE)
         textures = textures or []
         keep = [np.ascontiguousarray(t, dtype=np.float32) for t in textures]
@@ -56,8 +59,13 @@ class HostScene:
             tex[i].height, tex[i].width = t.shape[0], t.shape[1]
             tex[i].data = t.ctypes.data_as(C.POINTER(C.c_float))
         out = C.c_void_p()
-        capi.check(capi.lib().pt_scene_create(capi.np_ptr(tris), len(tris), capi.np_ptr(mats), len(mats),
-                                              tex, len(keep), C.byref(out)))
+        if strided:
+            layout = capi.TriangleLayout.of(tris.dtype)
+            capi.check(capi.lib().pt_scene_create_strided(capi.np_ptr(tris), len(tris), C.byref(layout), capi.np_ptr(mats),
+                                                          len(mats), tex, len(keep), C.byref(out)))
+        else:
+            capi.check(capi.lib().pt_scene_create(capi.np_ptr(tris), len(tris), capi.np_ptr(mats), len(mats),
+                                                  tex, len(keep), C.byref(out)))
         return HostScene(out.value)
 
     @property
@@ -298,6 +306,20 @@ class DevicePathTracer:
 
     def reloadWorld(self):
         capi.check(capi.lib().pt_upload_host_scene(self._h, self.hostScene_._h))
+
+    def uploadSceneStrided(self, triangles: np.ndarray, materials: np.ndarray, textures=None):
+        """reloadWorld() for a caller that keeps its own triangle records (the reference's
+        std::vector<Triangle> is 80-byte records): pt_upload_scene_strided with the array's own field offsets."""
+        tris = np.ascontiguousarray(triangles)
+        mats = np.ascontiguousarray(materials, dtype=capi.MATERIAL_DTYPE)
+        keep = [np.ascontiguousarray(t, dtype=np.float32) for t in (textures or [])]
+        tex = (capi.Texture * max(len(keep), 1))()
+        for i, t in enumerate(keep):
+            tex[i].height, tex[i].width = t.shape[0], t.shape[1]
+            tex[i].data = t.ctypes.data_as(C.POINTER(C.c_float))
+        layout = capi.TriangleLayout.of(tris.dtype)
+        capi.check(capi.lib().pt_upload_scene_strided(self._h, capi.np_ptr(tris), len(tris), C.byref(layout),
+                                                      capi.np_ptr(mats), len(mats), tex, len(keep)))
 
     def setFramebuffer(self, framebuffer: Framebuffer):
         self.framebuffer_ = framebuffer

@@ -275,7 +275,9 @@ def _read_ppm(path):
 
 
 @pytest.mark.parametrize("extra", [[], ["--streams", "2"], ["--streams", "4", "--algo", "dsfl", "--frames", "3"],
-                                   ["--streams", "4", "--algo", "dsdl", "--frames", "3", "--max-tasks-in-row", "4"]])
+                                   ["--streams", "4", "--algo", "dsdl", "--frames", "3", "--max-tasks-in-row", "4"],
+                                   # the intra-frame band queue: workers pull 8-row bands as their streams drain
+                                   ["--streams", "4", "--algo", "dqrb", "--frames", "3"], ["--streams", "3", "--algo", "dqrb"]])
 def test_cpp_driver_glb_to_ppm_matches_oracle(pt, box_oracle, gpu_device, tmp_path, extra):
     exe = os.path.join(ROOT, "multi-gpu-path-tracer_amd", "pt_render")
     assert os.path.exists(exe), "pt_render missing: __graft_entry__.build() builds it"
@@ -289,6 +291,25 @@ def test_cpp_driver_glb_to_ppm_matches_oracle(pt, box_oracle, gpu_device, tmp_pa
     ref = box_oracle.render(BOX_CAMERA, 96, 64, 4, 4, threads=8)
     assert np.array_equal(_read_ppm(str(out)), ref[0])                                   # any scheduler, same image
     assert np.array_equal(np.frombuffer(yuv.read_bytes(), np.uint8), ref[1])
+    import json
+    frames = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    assert all(f["segments"] == ref[2]["segments"] for f in frames)                      # every pixel rendered exactly once, every frame
+    if "dqrb" in extra:
+        assert all(f["tasks"] == 8 for f in frames)                                      # 64 rows in bands of 8
+
+
+def test_cpp_driver_dsdl_on_a_frame_too_thin_to_bisect(pt, box_oracle, gpu_device, tmp_path):
+    """a 16x8 frame is a 2x1 block grid; eight workers ask for three levels of bisection and two of them
+    cannot cut.  The degenerate branch must still yield 2^(depth - level) tasks (most of them empty), so that DSDL's new
+    layout is adopted instead of silently dropped -- and the image is the oracle's either way."""
+    exe = os.path.join(ROOT, "multi-gpu-path-tracer_amd", "pt_render")
+    out = tmp_path / "o.ppm"
+    cmd = [exe, "0", os.path.join(ROOT, "models", "cornell_box.glb"), "--cornell", "--width", "16", "--height", "8", "--spp", "4",
+           "--depth", "4", "--out", str(out), "--streams", "8", "--algo", "dsdl", "--frames", "3", "--max-tasks-in-row", "4"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    ref = box_oracle.render(BOX_CAMERA, 16, 8, 4, 4, threads=2)
+    assert np.array_equal(_read_ppm(str(out)), ref[0])
 
 
 def test_cpp_driver_error_behaviour(gpu_device, tmp_path):
@@ -300,10 +321,45 @@ def test_cpp_driver_error_behaviour(gpu_device, tmp_path):
     assert res.returncode == 99 and "no emissive face" in res.stderr
 
 
-def test_full_size_c2_properties(pt, box_scene, gpu_device):
-    """BASELINE.json configs[1] (1920x1080, 256 spp, 8 bounces) is too big for the oracle, so
-    check size-independent properties: determinism across frames, partition invariance
-    (whole frame vs 8-row bands of 3 interleaved 'ranks'), exact path count, counter ratios."""
+def _fullsize(name):
+    import json
+    with open(os.path.join(GOLD, "fullsize.json")) as f:
+        return json.load(f)[name]
+
+
+def _band_hashes(rgb, yuv, W, H, rows=8):
+    """As tests/golden/make_fullsize.py::band_hashes: names the rows when a full-size frame differs."""
+    out = []
+    rgb = rgb.reshape(H, W * 3)
+    yuv = yuv.reshape(-1)
+    y = yuv[:W * H].reshape(H, W)
+    u = yuv[W * H:W * H + W * H // 4].reshape(H // 2, W // 2)
+    v = yuv[W * H + W * H // 4:].reshape(H // 2, W // 2)
+    for r0 in range(0, H, rows):
+        r1 = min(H, r0 + rows)
+        h = hashlib.sha256()
+        for part in (rgb[r0:r1], y[r0:r1], u[(r0 + 1) // 2:(r1 + 1) // 2], v[(r0 + 1) // 2:(r1 + 1) // 2]):
+            h.update(np.ascontiguousarray(part).tobytes())
+        out.append(h.hexdigest()[:16])
+    return out
+
+
+def _assert_equals_fullsize_fixture(name, rgb, yuv, cnt):
+    g = _fullsize(name)
+    W, H = g["params"][:2]
+    bands = _band_hashes(rgb, yuv, W, H)
+    bad = [i for i, (a, b) in enumerate(zip(bands, g["band_sha16"])) if a != b]
+    assert not bad, "%s: %d of %d 8-row bands differ from the oracle's frame, first band %d" % (name, len(bad), len(bands), bad[0])
+    assert hashlib.sha256(rgb.tobytes() + yuv.tobytes()).hexdigest() == g["sha256_rgb_yuv"]
+    assert {k: cnt[k] for k in g["counters"]} == g["counters"]
+
+
+def test_full_size_c2_equals_the_oracle_and_properties(pt, box_scene, gpu_device):
+    """BASELINE.json configs[1] (1920x1080, 256 spp, 8 bounces), the configuration bench.py runs, in the default walk:
+    the frame's bytes (sha256 over RGB || YUV, and per 8-row band) and all five work counters equal the ORACLE's
+    full-size render (tests/golden/fullsize.json, made by make_fullsize.py: 1.33e9 segments on the CPU), plus the
+    size-independent properties: determinism across frames, partition invariance (whole frame vs 8-row bands of 3
+    interleaved 'ranks'), exact path count, counter ratios."""
     W, H, spp, depth = 1920, 1080, 256, 8
     fb = pt.Framebuffer(pt.Resolution(W, H))
     tr = pt.DevicePathTracer(0, spp, depth, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
@@ -311,6 +367,7 @@ def test_full_size_c2_properties(pt, box_scene, gpu_device):
     tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
     h1 = hashlib.sha256(fb.rgb_host().tobytes() + fb.yuv_host().tobytes()).hexdigest()
     c1 = tr.readCounters()
+    _assert_equals_fullsize_fixture("box_1920x1080_256spp_8b", fb.rgb_host(), fb.yuv_host(), c1)
     assert c1["paths"] == W * H * spp
     assert abs(c1["segments"] / c1["paths"] - 2.504) < 0.02
     assert abs(c1["box_tests"] / c1["segments"] - 14.3) < 0.15 and abs(c1["tri_tests"] / c1["segments"] - 16.8) < 0.17
@@ -325,6 +382,74 @@ def test_full_size_c2_properties(pt, box_scene, gpu_device):
     img = fb.rgb_host()
     assert img.mean() > 10 and img[:, :, 0].mean() != img[:, :, 1].mean()        # a lit, coloured Cornell box
     tr.close()
+
+
+@pytest.mark.parametrize("bvh", [0, 1])
+def test_full_size_duck_frame_equals_the_oracle(pt, duck_scene, gpu_device, bvh):
+    """configs[2]'s scene and frame size (1920x1080, 8 bounces) at 16 spp, the sample count the oracle finishes in
+    minutes: bytes and counters of the reference-tree walk equal the oracle's full-size frame; the SAH tree gives the
+    same bytes, paths, segments and light tests (its box / triangle test counts are its own)."""
+    g = _fullsize("duck_1920x1080_16spp_8b")
+    W, H, spp, depth = g["params"]
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), duck_scene, fb, pt.CameraConfig(DUCK_CAMERA[0], DUCK_CAMERA[1]), bvhMode=bvh)
+    tr.resetCounters()
+    tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+    cnt = tr.readCounters()
+    if bvh == 0:
+        _assert_equals_fullsize_fixture("duck_1920x1080_16spp_8b", fb.rgb_host(), fb.yuv_host(), cnt)
+    else:
+        assert hashlib.sha256(fb.rgb_host().tobytes() + fb.yuv_host().tobytes()).hexdigest() == g["sha256_rgb_yuv"]
+        assert all(cnt[k] == g["counters"][k] for k in ("paths", "segments", "light_tests"))
+        assert cnt["tri_tests"] * 50 < g["counters"]["tri_tests"]
+    tr.close()
+
+
+def test_reference_80_byte_triangles_render_the_golden_box(pt, box_scene, gpu_device):
+    """VERDICT r2 weak 9 / INTEGRATION.md 2: the reference's std::vector<Triangle> is 80-byte records (float2 is 8-byte
+    aligned), handed to the C ABI through pt_upload_scene_strided with PT_TRIANGLE_LAYOUT_REFERENCE's offsets; padding
+    bytes hold junk.  The frame must be the golden box, byte for byte, counters included."""
+    capi = pt.capi
+    g = np.load(os.path.join(GOLD, "box_160x90_8spp_8b.npz"))
+    W, H, spp, depth = [int(v) for v in g["params"]]
+    tris = box_scene.triangles
+    raw = np.full(len(tris) * 80, 0xCD, np.uint8)
+    rec = raw.view(capi.REFERENCE_TRIANGLE_DTYPE)
+    for v in ("v0", "v1", "v2"):
+        rec[v]["position"], rec[v]["texCoords"] = tris[v]["position"], tris[v]["texCoords"]
+    rec["textureIdx"], rec["materialIdx"] = tris["textureIdx"], tris["materialIdx"]
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), box_scene, fb, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
+    lay = capi.TriangleLayout.of(rec.dtype)
+    assert (lay.stride, list(lay.position), list(lay.texCoords), lay.textureIdx, lay.materialIdx) == (80, [0, 24, 48], [16, 40, 64], 72, 76)
+    # re-loaded through the documented route for the reference's own records
+    tr.uploadSceneStrided(rec, box_scene.materials, box_scene.textures)
+    tr.resetCounters()
+    tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+    assert np.array_equal(fb.rgb_host(), g["rgb"]) and np.array_equal(fb.yuv_host(), g["yuv"])
+    c = tr.readCounters()
+    assert [c[k] for k in ("paths", "segments", "box_tests", "tri_tests", "light_tests")] == g["counters"][:5].tolist()
+    # the cast INTEGRATION.md used to show (80-byte records read with a 68-byte stride) is a different scene
+    wrong = np.frombuffer(raw[:len(tris) * 68].tobytes(), capi.TRIANGLE_DTYPE)
+    assert wrong.tobytes() != tris.tobytes()
+    tr.close()
+
+
+def test_bench_without_a_launcher_runs_two_ranks(gpu_device):
+    """VERDICT r2 missing 2: `python bench.py --gpus 2` with no torchrun must start two ranks itself (a child
+    torch.distributed.run) and print n_gpus = ranks = 2 -- here as a rehearsal (both ranks on the one GPU, gloo)."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--config", "c1",
+                          "--steps", "2", "--warmup", "1", "--no-host-visible"], capture_output=True, text=True, timeout=900,
+                         cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"].startswith("gloo")
+    assert d["segments_per_frame"] == 5903674                 # C1's exact count (tests/golden/box_400x400_16spp_4b.npz)
 
 
 @pytest.mark.parametrize("bvh", [0, 1])
@@ -439,9 +564,36 @@ def test_native_pack_equals_python_pack_bands_and_round_trips(pt, box_scene, gpu
     owner = (C.c_int * len(ragged))(*([0] * len(ragged)))
     pt.capi.check(lib.pt_gather_frame(g, _tasks_c(pt, ragged), owner, len(ragged), pt.capi.np_ptr(host_rgb), pt.capi.np_ptr(host_yuv)))
     assert np.array_equal(host_rgb, rgb0.cpu().numpy()) and np.array_equal(host_yuv, yuv0.cpu().numpy())
-    with pytest.raises(pt.capi.PtError):
-        pt.capi.check(lib.pt_gather_create((C.c_void_p * 2)(tr._h, tr._h), 2, C.byref(C.c_void_p())))      # the same GPU twice
+    name = C.create_string_buffer(256)
+    pt.capi.check(lib.pt_gather_transport(g, name, 256))
+    assert name.value == b"none"
     pt.capi.check(lib.pt_gather_destroy(g))
+    # A group of TWO engines (both on the one GPU of this box, each with a framebuffer of its own): RCCL wants one rank
+    # per GPU, so the group takes its peer-copy transport (the fallback of a host without a usable librccl) and the whole
+    # multi-device flow of pt_gather_frame runs -- every peer packs its rectangles, the strings travel to engine 0, engine
+    # 0 scatters them and hands the frame to the host.  Engine 1 renders the rectangles engine 0 does not.
+    fb2 = pt.Framebuffer(pt.Resolution(W, H))
+    tr2 = pt.DevicePathTracer(0, spp, depth, (8, 8), box_scene, fb2, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]))
+    fb.rgb.zero_(); fb.yuv.zero_()
+    own = [0, 1, 1, 0, 1]
+    for t, o in zip(ragged, own):
+        (tr if o == 0 else tr2).renderTaskAsync(t)
+    tr.waitForRenderTask(); tr2.waitForRenderTask()
+    assert not torch.equal(fb.rgb, rgb0)                                             # engine 0 holds only its own part
+    g2 = C.c_void_p()
+    pt.capi.check(lib.pt_gather_create((C.c_void_p * 2)(tr._h, tr2._h), 2, C.byref(g2)))
+    pt.capi.check(lib.pt_gather_transport(g2, name, 256))
+    assert name.value.startswith(b"peer-copy (one GPU is listed more than once")
+    for frame in range(2):                                                           # staging buffers are reused
+        host_rgb[:] = 0; host_yuv[:] = 0
+        pt.capi.check(lib.pt_gather_frame(g2, _tasks_c(pt, ragged), (C.c_int * len(ragged))(*own), len(ragged),
+                                          pt.capi.np_ptr(host_rgb), pt.capi.np_ptr(host_yuv)))
+        assert np.array_equal(host_rgb, rgb0.cpu().numpy()) and np.array_equal(host_yuv, yuv0.cpu().numpy())
+    bad_owner = (C.c_int * len(ragged))(0, 1, 2, 0, 1)
+    with pytest.raises(pt.capi.PtError):
+        pt.capi.check(lib.pt_gather_frame(g2, _tasks_c(pt, ragged), bad_owner, len(ragged), pt.capi.np_ptr(host_rgb), pt.capi.np_ptr(host_yuv)))
+    pt.capi.check(lib.pt_gather_destroy(g2))
+    tr2.close()
     tr.close()
 
 

