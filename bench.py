@@ -59,6 +59,10 @@ def kernel_build_id():
     for name in ("pt_device.hip", "pt_walk.h", "pt_shade.h", "pt_math.h", "pt_kernels.h", "pt_internal.h", "Makefile"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
+    variant = os.environ.get("PTAMD_LIBRARY")
+    if variant:                 # a diagnostic variant build (tools/*.sh): never the same build as a committed profile's
+        with open(variant, "rb") as f:
+            h.update(b"variant:" + hashlib.sha256(f.read()).digest())
     return h.hexdigest()[:16]
 
 
@@ -69,7 +73,8 @@ def matching_profile(config, workload, build_id):
     (None, None, False).  The work of a frame is deterministic (per-pixel seeds), so the per-launch counts of a
     profile of the same build hold for every launch of this run; what this run measures itself is the time."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pmc_summary.json" % config)), key=os.path.getmtime)
+    # by name: the round / step tag leads the file name (r02m_... < r03a_...); mtimes are arbitrary after a checkout
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pmc_summary.json" % config)))
     best = (None, None, False)
     for path in files:
         try:

@@ -9,7 +9,10 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptamd.so")
+# PTAMD_LIBRARY: a diagnostic VARIANT build (tools/timeline.sh, tools/stamps.sh, tools/exp_lib.sh build theirs beside
+# the product library and point here), so that no tool ever has to overwrite the product library in place.
+LIB_PATH = os.environ.get("PTAMD_LIBRARY") or os.path.join(_HERE, "libptamd.so")
+IS_VARIANT_BUILD = bool(os.environ.get("PTAMD_LIBRARY"))
 
 PT_OK = 0
 STATUS_NAMES = {

@@ -122,15 +122,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
 __device__ uint32_t g_timeline[4 * 131072];
 #endif
 
-template <bool kInPlace>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_WAVES, PT_DEAL_WAVES))) void render_kernel_dealt(RenderParams P)
+// The frame both dealt kernels share: persistent waves that draw their tiles from the launch's counter, convergent
+// trips (every lane stays until the wave's last pixel is done, so the item rounds have all 64 lanes), issue priority by
+// remaining samples, split tiles.  `Walk` supplies the traversal and the shading view of its kernel (MaskDealtWalk: the
+// box's, kWalk 4; StackDealtWalk: the duck's, kWalk 5).
+template <class Walk>
+__device__ __forceinline__ void render_dealt_body(const RenderParams &P, const Walk &Wk, const int lane)
 {
-    extern __shared__ float4 lds_raw[];
-    const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
-    const ShadeViewLds V = stage_shade_lds(P, LL.tail, tid, kBlock);      // the host picks this kernel only when the tables fit
-    const DealView D = deal_carve(P, V.end, tid, kBlock);
     // Split tiles (see render_sah_body): here a trip's cost is mostly the wave's (box walk, shading), so a part of 16
     // pixels still costs ~0.65 of the tile per trip -- worth it only when the tile's chain bounds the launch, i.e. for
     // a rank's share of a multi-GPU frame, where there are fewer tiles than wave slots (split_count_kernel decides).
@@ -164,8 +162,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
         // and the trip count itself, which is this tile's cost for the next launch's order
         unsigned long long wave_box = 0, wave_tri = 0;
         uint32_t wave_seg = 0, trips = 0;
-        // Issue priority by remaining work (P.lrpt; measured neutral): a wave that still has most of its samples
-        // ahead outranks one that is nearly done.
+        // Issue priority by remaining work (P.lrpt): a wave that still has most of its samples ahead outranks one that is
+        // nearly done -- persistent waves all have the same age, and without this some wave of every SIMD starves.
         int prio_now = 0;
         while (true) {
             const unsigned long long alive_mask = pt_ballot(alive);
@@ -189,8 +187,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
                 wave_seg += (uint32_t)__popcll(trace_mask);
                 trips++;
             }
-            const Hit h = traverse_uniform_dealt<kInPlace>(P, D, lane, trace, L.ro, L.rd, 0.001f, 3.402823466e+38f, wave_box, wave_tri);
-            if (trace) shade<false, ShadeViewLds>(L, P, V, h);
+            const Hit h = Wk.hit(P, lane, trace, L.ro, L.rd, wave_box, wave_tri);
+            if (trace) Wk.shade_hit(L, P, h);
         }
         KernargParams &E = *fresh_kernarg();
         if (in_frame) write_pixel(E, L.col, pixel_index);
@@ -212,99 +210,60 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
     }
 }
 
-// The stack walk with dealt sparse leaves (kWalk 5, traverse_uniform_stack_dealt): render_kernel_dealt's frame -- persistent
-// waves, convergent trips, issue priority, split tiles -- around the walk for trees of up to 4 096 inner nodes (the duck).
+// kWalk 4: the mask walk with dealt sparse leaves (traverse_uniform_dealt), shading tables, triangle and onb tables in LDS.
+template <bool kInPlace>
+struct MaskDealtWalk {
+    ShadeViewLds V;
+    DealView D;
+    __device__ __forceinline__ Hit hit(const RenderParams &P, int lane, bool trace, const v3 &ro, const v3 &rd,
+                                       unsigned long long &wave_box, unsigned long long &wave_tri) const
+    {
+        return traverse_uniform_dealt<kInPlace>(P, D, lane, trace, ro, rd, 0.001f, 3.402823466e+38f, wave_box, wave_tri);
+    }
+    __device__ __forceinline__ void shade_hit(PathState &L, const RenderParams &P, const Hit &h) const { shade<false, ShadeViewLds>(L, P, V, h); }
+};
+
+template <bool kInPlace>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_WAVES, PT_DEAL_WAVES))) void render_kernel_dealt(RenderParams P)
+{
+    extern __shared__ float4 lds_raw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
+    MaskDealtWalk<kInPlace> Wk;
+    Wk.V = stage_shade_lds(P, LL.tail, tid, kBlock);      // the host picks this kernel only when the tables fit
+    Wk.D = deal_carve(P, Wk.V.end, tid, kBlock);
+    render_dealt_body(P, Wk, lane);
+}
+
+// kWalk 5: the stack walk with dealt sparse leaves (traverse_uniform_stack_dealt) for trees of up to 4 096 inner nodes (the
+// duck): per-lane LDS stack, triangle records from memory.
 #ifndef PT_DEAL_STACK_WAVES
 #define PT_DEAL_STACK_WAVES 5
 #endif
+struct StackDealtWalk {
+    ShadeView V;
+    DealView32 D;
+    uint32_t *stack;
+    __device__ __forceinline__ Hit hit(const RenderParams &P, int lane, bool trace, const v3 &ro, const v3 &rd,
+                                       unsigned long long &wave_box, unsigned long long &wave_tri) const
+    {
+        return traverse_uniform_stack_dealt(P, D, lane, trace, ro, rd, 0.001f, 3.402823466e+38f, stack, kBlock, wave_box, wave_tri);
+    }
+    __device__ __forceinline__ void shade_hit(PathState &L, const RenderParams &P, const Hit &h) const { shade<false, ShadeView>(L, P, V, h); }
+};
+
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_STACK_WAVES, PT_DEAL_STACK_WAVES))) void render_kernel_dealt_stack(RenderParams P)
 {
     extern __shared__ float4 lds_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
-    const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
-    const DealView32 D = deal_carve32(P, V.end, tid);
-    uint32_t *stack = LL.stack + tid;
-    // Split tiles (see render_sah_body): here a trip's cost is mostly the wave's (box walk, shading), so a part of 16
-    // pixels still costs ~0.65 of the tile per trip -- worth it only when the tile's chain bounds the launch, i.e. for
-    // a rank's share of a multi-GPU frame, where there are fewer tiles than wave slots (split_count_kernel decides).
-    const uint32_t parts = (uint32_t)P.split_parts;
-    uint32_t n_split = 0, n_slots_all = 0;
-    {
-        KernargParams &K = *fresh_kernarg();
-        if (K.n_split) n_split = K.n_split[0];
-        n_slots_all = K.n_slots + n_split * (parts - 1u);
-    }
-    // Persistent waves: the launch has as many workgroups as the device holds at once, and every WAVE takes its next tile
-    // from a counter when its own tile is done.  With one workgroup per four tiles a finished wave's slot stayed empty until
-    // its three siblings were done too (5 % of the slots of a C2 frame), and the shading tables were staged 8 100 times.
-    while (true) {
-        KernargParams &K = *fresh_kernarg();
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(K.tile_next, 1u);
-        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-        if (slot >= n_slots_all) break;                    // every wave gets here: the counter only grows
-#ifdef PT_TIMELINE
-        const uint32_t tl_start = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
-        const SlotWork sw = slot_work(K, slot, n_split, parts, lane);
-        const int tile = sw.tile;
-        int x, y, pixel_index;
-        const bool in_frame = tile_pixel(K, tile, sw.tile_lane, x, y, pixel_index) && sw.lane_on;
-        PathState L;
-        path_init(L, P, pixel_index);
-        bool alive = in_frame && P.depth > 0;
-        // wave totals in scalar registers: box / triangle tests (as in the mask walk), segments (lanes that trace in a trip)
-        // and the trip count itself, which is this tile's cost for the next launch's order
-        unsigned long long wave_box = 0, wave_tri = 0;
-        uint32_t wave_seg = 0, trips = 0;
-        // Issue priority by remaining work (P.lrpt; measured neutral): a wave that still has most of its samples
-        // ahead outranks one that is nearly done.
-        int prio_now = 0;
-        while (true) {
-            const unsigned long long alive_mask = pt_ballot(alive);
-            if (alive_mask == 0ull) break;
-            if (P.lrpt) {
-                const int s_now = __builtin_amdgcn_readlane(L.s, (int)__builtin_ctzll(alive_mask));     // a tile's pixels progress within a few %
-                const int left4 = (P.spp - s_now) * 4;
-                const int want = left4 > 3 * P.spp ? 3 : left4 > 2 * P.spp ? 2 : left4 > P.spp ? 1 : 0;
-                if (want != prio_now) {
-                    prio_now = want;
-                    if (want == 3) __builtin_amdgcn_s_setprio(3);
-                    else if (want == 2) __builtin_amdgcn_s_setprio(2);
-                    else if (want == 1) __builtin_amdgcn_s_setprio(1);
-                    else __builtin_amdgcn_s_setprio(0);
-                }
-            }
-            bool trace = alive;
-            if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
-            const unsigned long long trace_mask = pt_ballot(trace);
-            if (trace_mask != 0ull) {                          // (the last trip of a wave only discovers that every pixel is done)
-                wave_seg += (uint32_t)__popcll(trace_mask);
-                trips++;
-            }
-            const Hit h = traverse_uniform_stack_dealt(P, D, lane, trace, L.ro, L.rd, 0.001f, 3.402823466e+38f, stack, kBlock, wave_box, wave_tri);
-            if (trace) shade<false, ShadeView>(L, P, V, h);
-        }
-        KernargParams &E = *fresh_kernarg();
-        if (in_frame) write_pixel(E, L.col, pixel_index);
-        L.n_paths = in_frame ? (P.depth == 0 ? (uint32_t)P.spp : (uint32_t)L.s) : 0u;      // samples started (depth 0: rays generated, untraced)
-        L.n_seg = 0;
-        flush_counters(E, L, lane, wave_box, wave_tri, wave_seg);
-        if (E.tile_cost && lane == 0) {
-            if (sw.is_part) atomicMax(&E.tile_cost[tile], trips);      // a tile's trips = those of its busiest pixel, in whichever part
-            else E.tile_cost[tile] = trips;
-        }
-#ifdef PT_TIMELINE
-        if (lane == 0 && slot < 131072u) {
-            g_timeline[4 * slot] = tl_start;
-            g_timeline[4 * slot + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-            g_timeline[4 * slot + 2] = (uint32_t)tile | (sw.is_part ? 0x80000000u : 0u);
-            g_timeline[4 * slot + 3] = trips;
-        }
-#endif
-    }
+    StackDealtWalk Wk;
+    Wk.V = stage_shade(P, LL.tail, tid, kBlock);
+    Wk.D = deal_carve32(P, Wk.V.end, tid);
+    Wk.stack = LL.stack + tid;
+    render_dealt_body(P, Wk, lane);
 }
 
 // Cooperative kernel for reference trees with big leaves (cornell_duck: one leaf of 1603 triangles, 2 120
@@ -752,6 +711,7 @@ struct TileSchedule {
     bool used = false;
     int busy = 0;                 // launches that hold this entry outside dev->mu (between choosing it and recording last_use)
     uint64_t stamp = 0;
+    uint64_t id = 0;              // unique per allocation: a recycled ADDRESS must never pass for the schedule it replaced
 };
 
 struct pt_device {
@@ -829,9 +789,10 @@ struct pt_device {
     uint64_t launches = 0;
     const char *last_kernel = "";  // what the latest render launch ran (pt_kernel_name_read)
     // latest row-band launch, for pt_band_costs_read: its schedule (null = no costs recorded) and geometry
-    TileSchedule *band_sched = nullptr;
+    uint64_t band_sched_id = 0;              // TileSchedule::id of the latest band launch's schedule (0 = none)
     int band_tiles_x = 0, band_tiles_y = 0, band_rows_last = 0, band_local_rows = 0;
-    TileSchedule *last_sched = nullptr;      // the latest launch's schedule (pt_split_tiles_read), and its stream
+    uint64_t last_sched_id = 0;              // TileSchedule::id of the latest launch's schedule (pt_split_tiles_read), and its stream
+    uint64_t schedule_ids = 0;
     hipStream_t last_sched_stream = nullptr;
     hipStream_t band_stream = nullptr;
 };
@@ -1419,6 +1380,7 @@ static TileSchedule *schedule_for(pt_device *dev, const RenderParams &P, unsigne
     memcpy(t->key, key, sizeof key);
     t->slots = slots;
     t->stamp = dev->schedule_clock;
+    t->id = ++dev->schedule_ids;
     // One stream-ordered allocation (hipMallocAsync: no device-wide synchronisation, so scheduling
     // policies that move their rectangles every frame, DSFL / DSDL, can afford a fresh schedule per launch)
     const size_t bytes = (((size_t)slots * sizeof(uint32_t)) + 255) & ~(size_t)255;
@@ -1615,9 +1577,9 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         std::lock_guard<std::mutex> lk(dev->mu);
         if (sched) sched->busy--;                // last_use is recorded: from here on hipEventQuery(last_use) tells when it is idle
         dev->last_kernel = choice.name;
-        dev->last_sched = sched; dev->last_sched_stream = hs;
+        dev->last_sched_id = sched ? sched->id : 0; dev->last_sched_stream = hs;
         if (P.band_rows > 0) {
-            dev->band_sched = sched; dev->band_tiles_x = P.tiles_x; dev->band_tiles_y = P.tiles_y;
+            dev->band_sched_id = sched ? sched->id : 0; dev->band_tiles_x = P.tiles_x; dev->band_tiles_y = P.tiles_y;
             dev->band_rows_last = P.band_rows; dev->band_local_rows = P.task_h; dev->band_stream = hs;
         }
         dev->pending.push_back(ev);
@@ -1748,10 +1710,15 @@ try {
         std::lock_guard<std::mutex> lk(dev->mu);
         tiles_x = dev->band_tiles_x; tiles_y = dev->band_tiles_y; band_rows = dev->band_rows_last; local_rows = dev->band_local_rows;
         hs = dev->band_stream;
-        for (TileSchedule *t : dev->schedules) if (t == dev->band_sched) sched = t;      // still cached?
+        for (TileSchedule *t : dev->schedules) if (dev->band_sched_id && t->id == dev->band_sched_id) sched = t;      // still cached? (by id: an evicted schedule's address can be reused)
         if (sched) sched->busy++;
     }
     if (!sched || tiles_y <= 0) return PT_OK;              // nothing recorded (tile schedule off, tiny launch, or evicted)
+    if ((size_t)tiles_x * (size_t)tiles_y > (size_t)sched->slots) {      // never index a cost buffer beyond its slots
+        std::lock_guard<std::mutex> lk(dev->mu);
+        sched->busy--;
+        return set_error(PT_ERR_INTERNAL, "pt_band_costs_read: the cached schedule does not match the band launch");
+    }
     struct Unpin { pt_device *d; TileSchedule *t; ~Unpin() { std::lock_guard<std::mutex> lk(d->mu); t->busy--; } } unpin{dev, sched};
     const int nb = (local_rows + band_rows - 1) / band_rows;
     if (nb > max_bands) return set_error(PT_ERR_INVALID, "pt_band_costs_read: output array too small");
@@ -1839,7 +1806,7 @@ try {
     {
         std::lock_guard<std::mutex> lk(dev->mu);
         hs = dev->last_sched_stream;
-        for (TileSchedule *t : dev->schedules) if (t == dev->last_sched) sched = t;      // still cached?
+        for (TileSchedule *t : dev->schedules) if (dev->last_sched_id && t->id == dev->last_sched_id) sched = t;      // still cached?
         if (sched) sched->busy++;
     }
     if (!sched) return PT_OK;

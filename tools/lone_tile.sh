@@ -3,9 +3,10 @@
 # duration inside the full frame.  usage: bash tools/lone_tile.sh [config=c4] [n=4]
 set -e
 cd $GRAFT_REPO_ROOT; CFG=${1:-c4}; N=${2:-4}
-cp multi-gpu-path-tracer_amd/libptamd.so /tmp/lib_keep.so
-make -C multi-gpu-path-tracer_amd/csrc -B EXTRA=-DPT_TIMELINE ../libptamd.so > /dev/null 2>&1
-python3 - $CFG $N <<'PY'
+# the variant is built BESIDE the product library and loaded through PTAMD_LIBRARY: nothing is overwritten, nothing to restore
+mkdir -p build/variants
+make -C multi-gpu-path-tracer_amd/csrc -B EXTRA=-DPT_TIMELINE OUT=../../build/variants/libptamd_timeline.so ../../build/variants/libptamd_timeline.so > /dev/null 2>&1
+PTAMD_LIBRARY=$PWD/build/variants/libptamd_timeline.so python3 - $CFG $N <<'PY'
 import os, sys, importlib, ctypes as C, numpy as np
 sys.path.insert(0, ".")
 import bench
@@ -48,4 +49,3 @@ for k in np.argsort(-a[:, 3].astype(np.int64))[:n_top]:
                 ms, n = tr.kernelTime(); worst = max(worst, ms / n)
         print("    as %dx%d parts: slowest part %.2f ms" % (w, h, worst))
 PY
-cp /tmp/lib_keep.so multi-gpu-path-tracer_amd/libptamd.so

@@ -4,8 +4,7 @@
 # `make -C multi-gpu-path-tracer_amd/csrc -B EXTRA=-DPT_STALE OUT=../../build/variants/libptamd_stale.so`).
 set -e
 cd $GRAFT_REPO_ROOT
-cp multi-gpu-path-tracer_amd/libptamd.so /tmp/lib_keep.so; cp build/variants/libptamd_stale.so multi-gpu-path-tracer_amd/libptamd.so
-python3 - "$@" <<'PY'
+PTAMD_LIBRARY=$PWD/build/variants/libptamd_stale.so python3 - "$@" <<'PY'
 import sys, importlib
 sys.path.insert(0, ".")
 import bench
@@ -24,4 +23,3 @@ for cfg in sys.argv[1:] or ["c4", "c3"]:
           (cfg, visits, c["box_tests"] // 2, stale, 100.0 * stale / max(visits, 1), visits / c["segments"], c["tri_tests"] / c["segments"]))
     mgr.reset() if hasattr(mgr, "reset") else None
 PY
-cp /tmp/lib_keep.so multi-gpu-path-tracer_amd/libptamd.so

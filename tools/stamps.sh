@@ -1,10 +1,12 @@
 #!/bin/bash
 # Diagnostic: build a stamped copy of the library (PT_STAMPS), run a tiny image so every wave has a
-# SIMD to itself, print where a lone wave's cycles go, then restore the normal build.
+# SIMD to itself, print where a lone wave's cycles go.  The stamped copy is built beside the product library
+# (build/variants/, loaded through PTAMD_LIBRARY): nothing is overwritten.
 set -e
 cd $GRAFT_REPO_ROOT
-make -C multi-gpu-path-tracer_amd/csrc -B EXTRA=-DPT_STAMPS ../libptamd.so > /dev/null 2>&1
-python3 - <<'PY'
+mkdir -p build/variants
+make -C multi-gpu-path-tracer_amd/csrc -B EXTRA=-DPT_STAMPS OUT=../../build/variants/libptamd_stamps.so ../../build/variants/libptamd_stamps.so > /dev/null 2>&1
+PTAMD_LIBRARY=$PWD/build/variants/libptamd_stamps.so python3 - <<'PY'
 import sys, importlib, ctypes as C
 sys.path.insert(0, ".")
 pt = importlib.import_module("multi-gpu-path-tracer_amd")
@@ -22,4 +24,3 @@ for (W, H) in [(64, 32), (1920, 1080)]:
     print(W, H, "kernel ms", ms, "segments", c["segments"], "stamps:", getattr(tr, "readStamps", lambda: None)())
     tr.close()
 PY
-make -C multi-gpu-path-tracer_amd/csrc -B ../libptamd.so > /dev/null 2>&1

@@ -4,9 +4,10 @@
 # usage: bash tools/timeline.sh <tag> [config=c2] [sah]   (c4 always uses the SAH tree)
 set -e
 cd $GRAFT_REPO_ROOT; TAG=${1:-c2}; CFG=${2:-c2}; SAH=${3:-}
-cp multi-gpu-path-tracer_amd/libptamd.so /tmp/lib_keep.so
-make -C multi-gpu-path-tracer_amd/csrc -B EXTRA=-DPT_TIMELINE ../libptamd.so > /dev/null 2>&1
-python3 - $TAG $CFG $SAH <<'PY'
+# the variant is built BESIDE the product library and loaded through PTAMD_LIBRARY: nothing is overwritten, nothing to restore
+mkdir -p build/variants
+make -C multi-gpu-path-tracer_amd/csrc -B EXTRA=-DPT_TIMELINE OUT=../../build/variants/libptamd_timeline.so ../../build/variants/libptamd_timeline.so > /dev/null 2>&1
+PTAMD_LIBRARY=$PWD/build/variants/libptamd_timeline.so python3 - $TAG $CFG $SAH <<'PY'
 import sys, importlib, ctypes as C, numpy as np
 sys.path.insert(0, ".")
 import bench
@@ -30,4 +31,3 @@ assert fn(tr._h, buf.ctypes.data, buf.size) == 0
 np.save("gpurun_out/timeline_%s.npy" % tag, buf.reshape(-1, 4))
 print("timeline", tag, cfg, tr.kernelName(), "kernel ms", ms / n, "tiles", slots)
 PY
-cp /tmp/lib_keep.so multi-gpu-path-tracer_amd/libptamd.so
