@@ -212,9 +212,10 @@ PT_API pt_status pt_stream_destroy(pt_device *dev, pt_stream stream);
 /* Work counters (new; the metric's numerator).  Read after a sync. */
 PT_API pt_status pt_counters_read(pt_device *dev, pt_counters *out);
 PT_API pt_status pt_counters_reset(pt_device *dev);
-/* All 8 raw counter words: [0..4] as pt_counters; [5..7] are only written by the diagnostic
- * PT_STAMPS build (tools/stamps.sh): longest wave lifetime, summed traversal cycles, summed
- * wave lifetimes, in shader-clock cycles.                                                */
+/* All 8 raw counter words: [0..4] as pt_counters; [5] = blocks of 8 stack entries the persistent SAH kernel moved from
+ * LDS to its overflow area in device memory (rare; tests use it to prove that path ran); [5..7] in the diagnostic
+ * PT_STAMPS build (tools/stamps.sh): longest wave lifetime, summed traversal cycles, summed wave lifetimes, in
+ * shader-clock cycles.                                                                    */
 PT_API pt_status pt_debug_counters_read(pt_device *dev, uint64_t out8[8]);
 /* How many of its dearest tiles the NEXT launch of the latest launch's rectangle hands to several waves each (SAH
  * kernel; 0 when the cost-ordered tile schedule is off, the launch was tiny or the walk is another).

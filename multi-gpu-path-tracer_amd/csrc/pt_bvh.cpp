@@ -599,4 +599,70 @@ bool collapse_sah_quads(const SahBvh &in, std::vector<NodePair> &quads2, uint32_
     return c.ok && (quads2.size() / 2) * 128ull < (1ull << 32);
 }
 
+bool quantise_sah_quads(const std::vector<NodePair> &quads2, std::vector<QuadQ> &out)
+{
+    const size_t nq = quads2.size() / 2;
+    out.assign(nq, QuadQ{});
+    bool ok = true;
+    for (size_t qi = 0; qi < nq; qi++) {
+        const NodePair &h0 = quads2[2 * qi], &h1 = quads2[2 * qi + 1];
+        const float *box[4] = {&h0.lxmin, &h0.lxmin + 6, &h1.lxmin, &h1.lxmin + 6};
+        const uint32_t link[4] = {h0.llink, h0.lcnt, h0.rlink, h0.rcnt};
+        QuadQ &q = out[qi];
+        bool present[4];
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int c = 0; c < 4; c++) {
+            present[c] = box[c][0] < INFINITY;             // absent children carry +inf on all six planes
+            if (!present[c]) continue;
+            for (int a = 0; a < 3; a++) {
+                if (!std::isfinite(box[c][2 * a]) || !std::isfinite(box[c][2 * a + 1])) ok = false;
+                mn[a] = std::min(mn[a], box[c][2 * a]); mx[a] = std::max(mx[a], box[c][2 * a + 1]);
+            }
+        }
+        if (!ok) return false;
+        float org[3] = {mn[0] < INFINITY ? mn[0] : 0.0f, mn[1] < INFINITY ? mn[1] : 0.0f, mn[2] < INFINITY ? mn[2] : 0.0f};
+        uint32_t ex[3];
+        for (int a = 0; a < 3; a++) {
+            // the smallest power of two whose 255-fold reaches the far side, found against the decode itself
+            int e = 1;                                     // biased exponent 1 = 2^-126
+            const float ext = mx[a] > org[a] ? mx[a] - org[a] : 0.0f;
+            if (ext > 0.0f) {
+                int eb;
+                (void)std::frexp(ext / 255.0f, &eb);        // ext / 255 = m * 2^eb, m in [0.5, 1): 2^eb >= ext / 255
+                e = std::min(std::max(eb + 127, 1), 254);
+            }
+            while (e < 254 && !(quadq_plane(255u, (uint32_t)e, org[a]) >= mx[a])) e++;
+            if (!(quadq_plane(255u, (uint32_t)e, org[a]) >= mx[a])) return false;
+            ex[a] = (uint32_t)e;
+        }
+        q.ox = org[0]; q.oy = org[1]; q.oz = org[2];
+        q.exps = ex[0] | ex[1] << 8 | ex[2] << 16;
+        for (int c = 0; c < 4; c++) {
+            q.lo[c] = q.hi[c] = 0;
+            if (!present[c]) { q.link[c] = 0xFFFFFFFFu; continue; }
+            // inner links are byte offsets of 128-byte records in quads2: here the records are 64 bytes
+            q.link[c] = (link[c] & 15u) ? link[c] : link[c] / 2u;
+            uint32_t byte[6];
+            for (int a = 0; a < 3; a++) {
+                union { uint32_t u; float f; } sc; sc.u = ex[a] << 23;
+                const float lo = box[c][2 * a], hi = box[c][2 * a + 1];
+                // low plane: the largest byte whose decoded plane is still <= lo; high plane: the smallest with >= hi
+                long bl = (long)std::floor((double)(lo - org[a]) / (double)sc.f);
+                bl = std::min(std::max(bl, 0l), 255l);
+                while (bl > 0 && !(quadq_plane((uint32_t)bl, ex[a], org[a]) <= lo)) bl--;
+                while (bl < 255 && quadq_plane((uint32_t)bl + 1u, ex[a], org[a]) <= lo) bl++;
+                long bh = (long)std::ceil((double)(hi - org[a]) / (double)sc.f);
+                bh = std::min(std::max(bh, 0l), 255l);
+                while (bh < 255 && !(quadq_plane((uint32_t)bh, ex[a], org[a]) >= hi)) bh++;
+                while (bh > 0 && quadq_plane((uint32_t)bh - 1u, ex[a], org[a]) >= hi) bh--;
+                if (!(quadq_plane((uint32_t)bl, ex[a], org[a]) <= lo) || !(quadq_plane((uint32_t)bh, ex[a], org[a]) >= hi)) return false;
+                byte[2 * a] = (uint32_t)bl; byte[2 * a + 1] = (uint32_t)bh;
+            }
+            q.lo[c] = byte[0] | byte[2] << 8 | byte[4] << 16 | byte[1] << 24;
+            q.hi[c] = byte[3] | byte[5] << 8;
+        }
+    }
+    return nq * 64ull < (1ull << 32);
+}
+
 } // namespace pt

@@ -344,7 +344,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
 // are walking -- until at least half of those that were walking have finished -- and (3) shading
 // the finished ones, while the stragglers keep their traversal state (pair, LDS stack, closest
 // hit) across trips.  Per ray the sequence of tests is exactly traverse_sah's.
-template <bool kWide>
+// kForm: 0 = NodePair records, 1 = the 4-wide form (128-byte records), 2 = the 4-wide form in 64-byte records (QuadQ)
+template <int kForm>
 __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 {
     extern __shared__ float4 lds_raw[];
@@ -352,7 +353,15 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
     const int lane = tid & (kWave - 1);
     const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
     const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
-    uint32_t *stack = LL.stack + tid;
+    // the top of every lane's stack in LDS, what a deep ray pushes beyond it in this wave's part of the launch's spill area
+    const SahStack stack = {LL.stack + tid, kBlock, P.stack_cap,
+                            P.stack_spill ? P.stack_spill + ((size_t)(blockIdx.x * kWavesPerBlock + (tid >> 6)) * (size_t)P.spill_blocks * 64 + (size_t)lane) * kSpillBlock
+                                          : nullptr,
+#ifdef PT_STALE
+                            nullptr};                          // (that diagnostic build keeps its own figures in counters[5..6])
+#else
+                            P.counters + 5};
+#endif
     // Persistent waves, as in render_kernel_dealt: every wave takes its next tile from the launch's counter.
     // Split tiles.  A pixel's samples are one chain, and on a scene like C4's terrain the few dearest tiles (rays skimming
     // the ground towards the horizon) cost five times the median: started first, they still end last, alone on the
@@ -421,13 +430,14 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
                 const int want_tri = pt_popc(tri_mask), want_node = pt_popc(pair_mask & ~tri_mask);
                 if (want_tri >= want_node) {
                     if (sah_wants_tri(W)) {
-                        if (kWide) (void)sahw_tri_step(P, W, L.ro, L.rd, 0.001f, stack, kBlock, L.n_tri);
+                        if (kForm != 0) (void)sahw_tri_step(P, W, L.ro, L.rd, 0.001f, stack, L.n_tri);
                         else (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
                     }
                 } else {
                     if (sah_wants_node(W)) {
-                        if (kWide) (void)sahw_node_step(P, W, L.ro, L.rd, stack, kBlock, L.n_box);
-                        else (void)sah_node_step(P, W, L.ro, L.rd, stack, kBlock, L.n_box);
+                        if (kForm == 2) (void)sahq_node_step(P, W, L.ro, L.rd, stack, L.n_box);
+                        else if (kForm == 1) (void)sahw_node_step(P, W, L.ro, L.rd, stack, L.n_box);
+                        else (void)sah_node_step(P, W, L.ro, L.rd, stack, L.n_box);
                     }
                 }
                 cost++;
@@ -471,10 +481,12 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 // and triangles stay in cache are issue-bound and gain from a sixth wave even at the price of a few
 // spills (C3 143 -> 136 ms); the 1 GB terrain is bound by memory latency per dependent step and loses
 // to the spills (C4 84 -> 88 ms), so it keeps the natural allocation.
-__global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P) { render_sah_body<false>(P); }
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_sah6(RenderParams P) { render_sah_body<false>(P); }
+__global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P) { render_sah_body<0>(P); }
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_sah6(RenderParams P) { render_sah_body<0>(P); }
 // the 4-wide form of the tree (RenderParams::sah == 2)
-__global__ __launch_bounds__(kBlock) void render_kernel_sahw(RenderParams P) { render_sah_body<true>(P); }
+__global__ __launch_bounds__(kBlock) void render_kernel_sahw(RenderParams P) { render_sah_body<1>(P); }
+// the 4-wide form in 64-byte records (RenderParams::sah == 3): trees beyond the caches
+__global__ __launch_bounds__(kBlock) void render_kernel_sahq(RenderParams P) { render_sah_body<2>(P); }
 
 // ---- known-answer kernels (bit-exactness contract) -----------------------------------
 __global__ void kat_arith_kernel(int op, const float *a, const float *b, float *o0, float *o1, size_t n)
@@ -738,6 +750,8 @@ struct pt_device {
     bool sah = false;             // uploaded with the opt-in SAH tree instead of the reference topology
     bool sah_wide = true;         // upload the SAH tree in its 4-wide form (PTAMD_SAH_WIDE=0: the pair form)
     bool sah_wide_on = false;     // ... and the uploaded scene has it
+    int sah_quant = -1;           // the 4-wide form in 64-byte records (QuadQ): -1 = for trees beyond 64 KB, 0 = never, 1 = always (PTAMD_SAH_QUANT)
+    bool sah_quant_on = false;    // ... and the uploaded scene has it
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
     int spec_pct = -1;            // ... and leaves the walk loop when <= this % of the walkers remain; -1 = by scene size (fill_params)
     int deal_cap = 768, deal_min = 48;   // dealt walk (kWalk 4): item list capacity per wave; in-place threshold (lanes)
@@ -772,7 +786,8 @@ struct pt_device {
     // per launch: the two timing events and, for the persistent kernels, the counter its waves take their tiles from.
     // The triple is reused only after the launch's second event has completed, so launches in flight on different
     // streams never share a counter.
-    struct LaunchEvents { hipEvent_t first = nullptr, second = nullptr; uint32_t *next = nullptr; };
+    struct LaunchEvents { hipEvent_t first = nullptr, second = nullptr; uint32_t *next = nullptr;
+                          uint32_t *spill = nullptr; size_t spill_bytes = 0; };      // spill: the launch's SahStack overflow area, grown on demand
     std::vector<LaunchEvents> pending, free_events;
     std::vector<uint32_t *> next_chunks;      // tile counters, 256 per allocation, one 64-byte line each
     size_t next_used = 0;
@@ -783,6 +798,7 @@ struct pt_device {
     int deal_split = 4;           // dealt kernel: likewise (PTAMD_DEAL_SPLIT: 0 off, 2, 4, 8)
     int sah_split = 16;           // SAH kernel: waves a critically dear tile is handed to (PTAMD_SAH_SPLIT: 0 off, 16, 32, 64)
     int resident_cap = 0;         // persistent kernels: at most this many workgroups per CU (PTAMD_RESIDENT; 0 = what fits)
+    int sah_stack_lds = 16;       // persistent SAH kernel: stack entries per lane kept in LDS, deeper ones spill to device memory (PTAMD_SAH_STACK: 0 = all in LDS, else 11..64)
     struct Resident { const void *kern; size_t lds; int blocks; };
     std::vector<Resident> resident_blocks;      // per kernel and LDS size: workgroups one CU holds (persistent grids)
     double ms_total = 0.0;
@@ -885,6 +901,7 @@ try {
     // out-of-range values are ignored
     if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;
     if (const char *e = getenv("PTAMD_SAH_WIDE")) d->sah_wide = atoi(e) != 0;
+    if (const char *e = getenv("PTAMD_SAH_QUANT")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->sah_quant = v; }
     if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 99) d->spec_pct = v; }   // 100 would leave the walk loop before its first step
     if (const char *e = getenv("PTAMD_DEAL")) d->deal_auto = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_LRPT")) d->lrpt = atoi(e) != 0;
@@ -896,6 +913,7 @@ try {
     if (const char *e = getenv("PTAMD_SPLIT_PCT")) { const int v = atoi(e); if (v >= 10 && v <= 1000) d->split_pct = v; }
     if (const char *e = getenv("PTAMD_DEAL_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 2 || v == 4 || v == 8) d->deal_split = v; }
     if (const char *e = getenv("PTAMD_SAH_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) d->sah_split = v; }
+    if (const char *e = getenv("PTAMD_SAH_STACK")) { const int v = atoi(e); if (v == 0 || (v >= 11 && v <= 64)) d->sah_stack_lds = v; }
     if (const char *e = getenv("PTAMD_RESIDENT")) { const int v = atoi(e); if (v >= 1 && v <= 16) d->resident_cap = v; }
     if (const char *e = getenv("PTAMD_FOLD_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 31) d->fold_bits = v; }
     if (const char *e = getenv("PTAMD_COOP")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->coop_mode = v; }
@@ -921,8 +939,8 @@ try {
     free_scene(dev);
     drop_schedules(dev);
     (void)hipFree(dev->d_counters);
-    for (auto &pr : dev->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-    for (auto &pr : dev->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto &pr : dev->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); (void)hipFree(pr.spill); }
+    for (auto &pr : dev->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); (void)hipFree(pr.spill); }
     for (uint32_t *c : dev->next_chunks) (void)hipFree(c);
     delete dev;
     return PT_OK;
@@ -1014,7 +1032,7 @@ try {
         for (size_t i = 0; i < n; i++) bvh.indices[i] = (int)i;
     }
     SahBvh sahbvh;
-    bool sah_wide_on = false;
+    bool sah_wide_on = false, sah_quant_on = false;
     if (sah) {
         build_sah_bvh(pos.data(), n, sahbvh);
         if (sahbvh.max_stack > 64) return set_error(PT_ERR_STACK, "SAH tree deeper than 64 levels");
@@ -1088,6 +1106,21 @@ try {
         sah_wide_on = dev->sah_wide && collapse_sah_quads(sahbvh, pairs, wide_stack) && wide_stack <= 64;
         if (sah_wide_on) {
             sahbvh.max_stack = wide_stack;       // entries a walk of the 4-wide form can have pushed at once
+            // All but toy trees take the 4-wide form at half the bytes (QuadQ: 8-bit child planes, rounded outwards): a visit is
+            // four per-lane 16-byte requests instead of seven, and on the 8.4 M-triangle terrain the vector-memory path was 70 %
+            // busy serving them (profiles/r03_c4_memory_path.json).  The decode costs ~48 instructions per visit: with the short
+            // LDS stack's fifth workgroup per CU, C4 55.4 -> 51.7 ms, C3 122.4 -> 119.0 ms; the Cornell box through the SAH tree
+            // (9 nodes, all in the scalar / L1 caches, purely issue-bound) 75.6 -> 79.2 ms, hence the size rule.
+            const size_t wide_bytes = pairs.size() * sizeof(NodePair) + n * sizeof(TriIsect);
+            if (dev->sah_quant == 1 || (dev->sah_quant < 0 && wide_bytes > ((size_t)64 << 10))) {
+                std::vector<QuadQ> qq;
+                if (quantise_sah_quads(pairs, qq)) {
+                    static_assert(sizeof(QuadQ) == sizeof(NodePair), "a QuadQ record travels as one NodePair-sized record");
+                    pairs.resize(qq.size());
+                    memcpy(pairs.data(), qq.data(), qq.size() * sizeof(QuadQ));
+                    sah_quant_on = true;
+                }
+            }
         } else {
             pairs = sahbvh.pairs;
             for (NodePair &q : pairs) {
@@ -1194,10 +1227,11 @@ try {
     dev->packed_queue = n < 65536;
     dev->sah = sah;
     dev->sah_wide_on = sah && sah_wide_on;
+    dev->sah_quant_on = sah && sah_wide_on && sah_quant_on;
     dev->sah_stack = sah ? sahbvh.max_stack : 0;
     if (sah && getenv("PTAMD_VERBOSE"))
         fprintf(stderr, "ptamd: SAH tree %zu pairs, %s form %zu records, walk stack %u entries\n", sahbvh.pairs.size(),
-                sah_wide_on ? "4-wide" : "pair", sah_wide_on ? pairs.size() / 2 : pairs.size(), sahbvh.max_stack);
+                sah_quant_on ? "4-wide 64-byte" : sah_wide_on ? "4-wide" : "pair", sah_wide_on && !sah_quant_on ? pairs.size() / 2 : pairs.size(), sahbvh.max_stack);
     dev->walk = std::max(choose_walk(dev), 0);
     dev->queue_entries = (int)std::min<uint32_t>(std::max<uint32_t>(dev->bvh.leaves + 1, 4), 12);
     dev->has_scene = true;
@@ -1328,7 +1362,7 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.n_pairs = (int)dev->n_pairs;
     P.n_tris = (int)dev->n_tris;
     P.queue_entries = dev->queue_entries;
-    P.sah = dev->sah ? (dev->sah_wide_on ? 2 : 1) : 0;
+    P.sah = dev->sah ? (dev->sah_quant_on ? 3 : dev->sah_wide_on ? 2 : 1) : 0;
     // How soon the SAH kernel's walk loop lets finished lanes shade and take their next segment.  Measured (tools/exp_pct.sh):
     // a tree that lives in the caches wants few, well-filled shading passes (C3: 40 % -> 128.8 ms; 50: 131.2, 65: 138.7);
     // a tree in HBM, whose every step waits on memory, wants its idle lanes refilled early (C4: 80 % -> 67.5 ms; 50: 72.2,
@@ -1342,6 +1376,8 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.deal_cap = 0; P.deal_min = dev->deal_min; P.any_tex = dev->any_tex ? 1 : 0; P.lrpt = dev->lrpt;
     P.tile_order = nullptr; P.tile_cost = nullptr; P.band_list = nullptr;
     P.legacy_mats = dev->d_legacy; P.spheres = dev->d_spheres; P.n_spheres = dev->n_spheres;
+    // SAH walks check for room before they push (SahStack): with the whole stack in LDS the check must never fire, hence + 3
+    P.stack_spill = nullptr; P.spill_blocks = 0; P.stack_cap = 0x3fffffff;      // whole stack in LDS: the check never fires
     if (dev->sah) P.stack_entries = (int)dev->sah_stack;
     P.queue_dwords = (dev->packed_queue && !dev->legacy_on) ? 1 : 2;      // the extension kernel uses the unpacked queue
     P.n_mats = (int)dev->n_mats;
@@ -1412,6 +1448,7 @@ static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool 
         (void)scene_bytes;      // round 1 picked the 6-wave build for cache-resident scenes; after round 2's diet the natural
                                 // (5-wave, spill-free) build is as fast there (C3 132.9 vs 133.8 ms) and faster on C4
         const bool six = dev->sah_waves == 6;
+        if (dev->sah_quant_on) return PT_KERNEL(dev::render_kernel_sahq);
         if (dev->sah_wide_on) return PT_KERNEL(dev::render_kernel_sahw);
         return six ? PT_KERNEL(dev::render_kernel_sah6) : PT_KERNEL(dev::render_kernel_sah);
     }
@@ -1474,6 +1511,12 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
                       (dev->coop_mode == 1 || (walk == 2 && dev->coop_mode < 0 && dev->bvh.max_leaf >= 64 &&
                                                tiles * dev::kWavesPerBlock <= 3ll * dev->max_waves));
     if (coop) { blocks = (unsigned)tiles; P.queue_entries = 10; P.queue_dwords = 1; P.deal_cap = 0; }   // LDS per thread: 2 x (float4 partial hit + visit rank)
+    if (walk == 3 && dev->sah_persistent && dev->sah_stack_lds > 0 && (int)dev->sah_stack > dev->sah_stack_lds) {
+        // The persistent SAH kernel keeps only the top of every lane's stack in LDS (SahStack, pt_walk.h): the worst-case
+        // bound of a deep tree (C4: 37 entries = 38 KB per workgroup) would otherwise cap its occupancy.
+        P.stack_entries = P.stack_cap = dev->sah_stack_lds;
+        P.spill_blocks = ((int)dev->sah_stack + 3 - dev->sah_stack_lds + dev::kSpillBlock - 1) / dev::kSpillBlock + 1;
+    }
     const size_t lds = lds_bytes(P, dev::kBlock, stage);
     const KernelChoice choice = pick_kernel(dev, walk, coop, stage, packed);
     const RenderKernel kern = choice.fn;
@@ -1554,6 +1597,16 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         int per_cu = resident_per_cu(dev, (const void *)kern, lds);
         if (dev->resident_cap > 0) per_cu = std::min(per_cu, dev->resident_cap);
         blocks = std::min(blocks, (unsigned)(dev->cu_count * per_cu));
+        if (P.spill_blocks > 0) {
+            // the launch's own overflow area for stacks deeper than their LDS part: one run of blocks per resident wave
+            const size_t need = (size_t)blocks * dev::kWavesPerBlock * (size_t)P.spill_blocks * 64 * dev::kSpillBlock * sizeof(uint32_t);
+            if (ev.spill_bytes < need) {
+                (void)hipFree(ev.spill); ev.spill = nullptr; ev.spill_bytes = 0;      // (recycled with its events: no launch is using it)
+                PT_HIP_LAUNCH(hipMalloc((void **)&ev.spill, need));
+                ev.spill_bytes = need;
+            }
+            P.stack_spill = ev.spill;
+        }
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     PT_HIP_LAUNCH(hipGetLastError());

@@ -111,6 +111,31 @@ void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out);
 // builder only makes at its depth limit).  max_stack = the most entries a walk can have pushed at once.
 bool collapse_sah_quads(const SahBvh &in, std::vector<NodePair> &quads2, uint32_t &max_stack);
 
+// The 4-wide form at HALF the bytes, for trees that do not fit the caches (C4: the walk is then bound by the number of
+// per-lane 16-byte requests the vector-memory path serves, profiles/r03_c4_memory_path.json): 64 B = four dwordx4 loads
+// instead of seven.  The four child boxes are 8-bit offsets from the node's origin in power-of-two units per axis:
+//   plane = fmaf((float)byte, 2^e_axis, origin_axis)
+// and quantise_sah_quads rounds every low plane DOWN and every high plane UP against exactly that expression, so a
+// decoded box always contains the box it stands for: the walk may enter a subtree it could have skipped (+ <1 % triangle
+// tests), never the other way round, and the closest hit -- min over (t, rank) of the triangles tested -- cannot change.
+struct QuadQ {
+    float ox, oy, oz;             // origin: the per-axis minimum over the node's children
+    uint32_t exps;                // biased binary exponents of the x | y << 8 | z << 16 units
+    uint32_t lo[4];               // per child: xlo | ylo << 8 | zlo << 16 | xhi << 24
+    uint32_t hi[4];               // per child: yhi | zhi << 8
+    uint32_t link[4];             // as in the 128-byte form with 64-byte node records (inner: byte offset, multiple of 64;
+                                  // leaf: byte offset of its first TriIsect | count); 0xFFFFFFFF = no such child
+};
+static_assert(sizeof(QuadQ) == 64, "QuadQ is one 64-byte record");
+// quads2 = collapse_sah_quads' output.  Returns false if some box cannot be represented (non-finite bounds).
+bool quantise_sah_quads(const std::vector<NodePair> &quads2, std::vector<QuadQ> &out);
+// The decode the device uses (pt_walk.h sahq_node_step), for the builder's outward rounding and the CPU checks.
+inline float quadq_plane(uint32_t byte, uint32_t biased_exp, float origin)
+{
+    union { uint32_t u; float f; } s; s.u = biased_exp << 23;
+    return __builtin_fmaf((float)byte, s.f, origin);
+}
+
 struct TexDesc { int32_t w, h; uint32_t offset /* in floats */, pad; };
 
 } // namespace pt

@@ -43,7 +43,10 @@ struct RenderParams {
     const int *band_list;             // non-null: task rows are the rows of these bands, in this order (pt_render_band_list_async)
     int spp;
     unsigned depth;
-    int stack_entries;                // per-lane LDS stack slots (max_stack - 1)
+    int stack_entries;                // per-lane LDS stack slots (reference tree: max_stack - 1; SAH tree: its bound, or fewer with stack_spill)
+    int stack_cap;                    // SAH walks: entries a lane may hold in LDS before it spills (SahStack::cap); huge when everything fits
+    uint32_t *stack_spill;            // persistent SAH kernel: where stacks deeper than stack_entries continue (SahStack), or null
+    int spill_blocks;                 // ... blocks of 8 entries per lane in it
     int queue_entries;                // per-lane LDS leaf-queue slots (>= 2; 0 for the wave-uniform walks)
     int queue_dwords;                 // dwords per queue entry (1 packed, 2 otherwise)
     int n_pairs, n_tris;              // array lengths (for LDS staging)

@@ -674,6 +674,7 @@ struct SahWalk {
                                   // recomputes them for the winner, same arithmetic, same operands -> the same bits
     v3 inv;
     uint32_t k0, n0, k1, n1;      // pending leaf triangles (byte offset, count): range 0 first, then range 1
+    uint32_t spill;               // blocks of 8 entries this lane's stack has moved out of LDS (SahStack; almost always 0)
 #ifdef PT_STALE
     uint32_t stale, visits;       // diagnostic build: node visits that found both children beyond the closest hit / all visits
 #endif
@@ -681,6 +682,53 @@ struct SahWalk {
     // trips is materialised as 0 / 1 and compared again for every ballot.)
 };
 constexpr uint32_t kNoPair = 0xFFFFFFFFu;
+
+// The walk's per-lane stack.  LDS holds the top `cap` entries of every lane ([entry][lane]: conflict-free); what a deep
+// ray pushes beyond that moves, eight entries at a time, to a per-lane area in device memory (`spill`, one block per
+// (wave, block index, lane): 32 contiguous bytes) and comes back when the lane has popped down to it.  The worst-case
+// bound of the 8 M-triangle terrain's tree is 37 entries per lane, 38 KB per workgroup, which held the SAH kernel to four
+// waves per SIMD; rays rarely hold more than a dozen.  One compare + one untaken scalar branch per node visit and per pop.
+// cap = 2^30 and spill = null where the whole stack is in LDS (the simple SAH kernels, the KAT kernel, PTAMD_SAH_STACK=0):
+// the checks below then never fire.
+struct SahStack {
+    uint32_t *lds;                // this lane's column
+    int stride;                   // lanes per entry row (workgroup size)
+    int cap;                      // entries per lane in LDS
+    uint32_t *spill;              // this lane's first block in device memory (block b at spill + b * 64 * 8 dwords), or null
+    unsigned long long *n_spills; // counts blocks moved out (counters[5], read by pt_debug_counters_read: tests prove the path ran), or null
+};
+constexpr int kSpillBlock = 8;
+
+// Makes room for n more pushes (n <= 3 < kSpillBlock <= cap / 2).
+__device__ __forceinline__ void sah_stack_reserve(const SahStack &S, SahWalk &W, int n)
+{
+    if (__builtin_expect(pt_ballot(W.sp + n > S.cap) != 0ull, 0)) {
+        if (W.sp + n > S.cap) {
+            uint32_t *g = S.spill + (size_t)W.spill * (64 * kSpillBlock);
+            uint32_t e[kSpillBlock];
+#pragma unroll
+            for (int k = 0; k < kSpillBlock; k++) e[k] = S.lds[k * S.stride];
+            reinterpret_cast<uint4 *>(g)[0] = make_uint4(e[0], e[1], e[2], e[3]);
+            reinterpret_cast<uint4 *>(g)[1] = make_uint4(e[4], e[5], e[6], e[7]);
+            for (int k = kSpillBlock; k < W.sp; k++) S.lds[(k - kSpillBlock) * S.stride] = S.lds[k * S.stride];
+            W.sp -= kSpillBlock;
+            W.spill++;
+            if (S.n_spills) atomicAdd(S.n_spills, 1ull);
+        }
+    }
+}
+// The lane's LDS part is empty: fetch its latest block back, if there is one.  Returns false when the whole stack is empty.
+__device__ __forceinline__ bool sah_stack_refill(const SahStack &S, SahWalk &W)
+{
+    if (W.spill == 0) return false;
+    W.spill--;
+    const uint32_t *g = S.spill + (size_t)W.spill * (64 * kSpillBlock);
+    const uint4 a = reinterpret_cast<const uint4 *>(g)[0], b = reinterpret_cast<const uint4 *>(g)[1];
+    S.lds[0 * S.stride] = a.x; S.lds[1 * S.stride] = a.y; S.lds[2 * S.stride] = a.z; S.lds[3 * S.stride] = a.w;
+    S.lds[4 * S.stride] = b.x; S.lds[5 * S.stride] = b.y; S.lds[6 * S.stride] = b.z; S.lds[7 * S.stride] = b.w;
+    W.sp = kSpillBlock;
+    return true;
+}
 // What a lane of the SAH walk wants next: a triangle test, a node visit, or nothing (walk complete).
 __device__ __forceinline__ bool sah_wants_tri(const SahWalk &W) { return W.n0 != 0; }
 __device__ __forceinline__ bool sah_wants_node(const SahWalk &W) { return (W.n0 == 0) & (W.pair != kNoPair); }
@@ -692,6 +740,7 @@ __device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
     W.inv = mk3(pt_rcp(d.x), pt_rcp(d.y), pt_rcp(d.z));
     W.best_off = 0xFFFFFFFFu;
     W.k0 = W.n0 = W.k1 = W.n1 = 0;
+    W.spill = 0;
 }
 
 // One MICRO-step of the SAH walk: either one Moller-Trumbore test (if this lane has leaf triangles
@@ -733,9 +782,12 @@ __device__ __forceinline__ bool sah_tri_step(const RenderParams &P, SahWalk &W, 
     return sah_walking(W);
 }
 
-__device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, uint32_t *stack, int stride,
+__device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, const SahStack &S,
                                               uint32_t &n_box)
 {
+    uint32_t *const stack = S.lds;
+    const int stride = S.stride;
+    sah_stack_reserve(S, W, 1);
     const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
     const float4 a = np[0], b = np[1], c = np[2], lf = np[3];
     const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
@@ -784,7 +836,7 @@ __device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W,
         W.pair = left_first ? llink : rlink;
     } else if (gl || gr) {
         W.pair = gl ? llink : rlink;
-    } else if (W.sp == 0) {
+    } else if (W.sp == 0 && !sah_stack_refill(S, W)) {
         W.pair = kNoPair;
     } else {
         W.sp--;
@@ -804,19 +856,19 @@ __device__ __forceinline__ void sahw_take(SahWalk &W, uint32_t x)
     if (x & 15u) { W.k0 = x & ~15u; W.n0 = x & 15u; }
     else W.pair = x;
 }
-__device__ __forceinline__ void sahw_pop(SahWalk &W, const uint32_t *stack, int stride)
+__device__ __forceinline__ void sahw_pop(SahWalk &W, const SahStack &S)
 {
-    if (W.sp > 0) {
+    if (W.sp > 0 || sah_stack_refill(S, W)) {
         W.sp--;
-        sahw_take(W, stack[W.sp * stride]);
+        sahw_take(W, S.lds[W.sp * S.stride]);
     }
 }
 
-__device__ __forceinline__ bool sahw_tri_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin, const uint32_t *stack, int stride,
+__device__ __forceinline__ bool sahw_tri_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin, const SahStack &S,
                                               uint32_t &n_tri)
 {
     (void)sah_tri_step(P, W, o, d, tmin, n_tri);          // (k1 / n1 are never set in this form: the range just ends)
-    if ((W.n0 == 0) & (W.pair == kNoPair)) sahw_pop(W, stack, stride);
+    if ((W.n0 == 0) & (W.pair == kNoPair)) sahw_pop(W, S);
     return sah_walking(W);
 }
 
@@ -837,8 +889,11 @@ __device__ __forceinline__ void sahw_order(float &ka, uint32_t &la, float &kb, u
     const uint32_t l = swap ? lb : la; lb = swap ? la : lb; la = l;
 }
 
-__device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, uint32_t *stack, int stride, uint32_t &n_box)
+__device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, const SahStack &S, uint32_t &n_box)
 {
+    uint32_t *const stack = S.lds;
+    const int stride = S.stride;
+    sah_stack_reserve(S, W, 3);
     const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
     const float4 q0 = np[0], q1 = np[1], q2 = np[2], lk = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
     const v3 inv = W.inv;
@@ -859,7 +914,51 @@ __device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W
     if (k2 < inf) { stack[W.sp * stride] = l2; W.sp++; }
     if (k1 < inf) { stack[W.sp * stride] = l1; W.sp++; }
     if (k0 < inf) sahw_take(W, l0);
-    else sahw_pop(W, stack, stride);
+    else sahw_pop(W, S);
+    return sah_walking(W);
+}
+
+// ---- the 4-wide form in 64-byte records (QuadQ, pt_internal.h; RenderParams::sah == 3) ------------------------------------
+// Same walk, same stack entries; a visit costs four dwordx4 requests per lane instead of seven, plus the decode: the planes
+// are fmaf(byte, unit, origin), exactly the expression the host rounded outwards against, then the slab arithmetic of
+// sahw_slab.  (Folding the decode into the slab -- byte * (unit * inv) + (origin - o) * inv -- would save a third of the
+// arithmetic and lose the cancellation-free subtraction plane - o: for rays nearly parallel to an axis the two products
+// are huge and their sum is noise.)
+__device__ __forceinline__ void sahq_slab(uint32_t lo, uint32_t hi, float ox, float oy, float oz, float sx, float sy, float sz, v3 o, v3 inv,
+                                          float tbest, bool present, float &key)
+{
+    const float xmin = fmaf((float)(lo & 0xffu), sx, ox), ymin = fmaf((float)((lo >> 8) & 0xffu), sy, oy), zmin = fmaf((float)((lo >> 16) & 0xffu), sz, oz);
+    const float xmax = fmaf((float)(lo >> 24), sx, ox), ymax = fmaf((float)(hi & 0xffu), sy, oy), zmax = fmaf((float)((hi >> 8) & 0xffu), sz, oz);
+    float k;
+    sahw_slab(xmin, xmax, ymin, ymax, zmin, zmax, o, inv, tbest, k);
+    key = present ? k : __builtin_inff();
+}
+
+__device__ __forceinline__ bool sahq_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, const SahStack &S, uint32_t &n_box)
+{
+    uint32_t *const stack = S.lds;
+    const int stride = S.stride;
+    sah_stack_reserve(S, W, 3);
+    const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2], lk = np[3];
+    const uint32_t exps = __float_as_uint(q0.w);
+    const float sx = __uint_as_float((exps & 0xffu) << 23), sy = __uint_as_float(((exps >> 8) & 0xffu) << 23), sz = __uint_as_float(((exps >> 16) & 0xffu) << 23);
+    uint32_t l0 = __float_as_uint(lk.x), l1 = __float_as_uint(lk.y), l2 = __float_as_uint(lk.z), l3 = __float_as_uint(lk.w);
+    const v3 inv = W.inv;
+    float k0, k1, k2, k3;
+    sahq_slab(__float_as_uint(q1.x), __float_as_uint(q2.x), q0.x, q0.y, q0.z, sx, sy, sz, o, inv, W.tbest, l0 != 0xFFFFFFFFu, k0);
+    sahq_slab(__float_as_uint(q1.y), __float_as_uint(q2.y), q0.x, q0.y, q0.z, sx, sy, sz, o, inv, W.tbest, l1 != 0xFFFFFFFFu, k1);
+    sahq_slab(__float_as_uint(q1.z), __float_as_uint(q2.z), q0.x, q0.y, q0.z, sx, sy, sz, o, inv, W.tbest, l2 != 0xFFFFFFFFu, k2);
+    sahq_slab(__float_as_uint(q1.w), __float_as_uint(q2.w), q0.x, q0.y, q0.z, sx, sy, sz, o, inv, W.tbest, l3 != 0xFFFFFFFFu, k3);
+    n_box += 4;
+    sahw_order(k0, l0, k1, l1); sahw_order(k0, l0, k2, l2); sahw_order(k0, l0, k3, l3);
+    const float inf = __builtin_inff();
+    W.pair = kNoPair;
+    if (k3 < inf) { stack[W.sp * stride] = l3; W.sp++; }
+    if (k2 < inf) { stack[W.sp * stride] = l2; W.sp++; }
+    if (k1 < inf) { stack[W.sp * stride] = l1; W.sp++; }
+    if (k0 < inf) sahw_take(W, l0);
+    else sahw_pop(W, S);
     return sah_walking(W);
 }
 
@@ -882,10 +981,10 @@ __device__ __forceinline__ Hit sah_hit(const RenderParams &P, const SahWalk &W, 
 }
 
 __device__ __forceinline__ bool sah_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin,
-                                         uint32_t *stack, int stride, uint32_t &n_box, uint32_t &n_tri)
+                                         const SahStack &S, uint32_t &n_box, uint32_t &n_tri)
 {
     if (W.n0 != 0) return sah_tri_step(P, W, o, d, tmin, n_tri);
-    return sah_node_step(P, W, o, d, stack, stride, n_box);
+    return sah_node_step(P, W, o, d, S, n_box);
 }
 
 __device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, float tmin, float tmax0,
@@ -893,10 +992,13 @@ __device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, f
 {
     SahWalk W;
     sah_begin(W, d, tmax0);
-    if (P.sah == 2) {
-        while (W.n0 != 0 ? sahw_tri_step(P, W, o, d, tmin, stack, stride, n_tri) : sahw_node_step(P, W, o, d, stack, stride, n_box)) {}
+    const SahStack S = {stack, stride, P.stack_cap, nullptr, nullptr};      // the whole stack in LDS: stack_cap is out of reach
+    if (P.sah == 3) {
+        while (W.n0 != 0 ? sahw_tri_step(P, W, o, d, tmin, S, n_tri) : sahq_node_step(P, W, o, d, S, n_box)) {}
+    } else if (P.sah == 2) {
+        while (W.n0 != 0 ? sahw_tri_step(P, W, o, d, tmin, S, n_tri) : sahw_node_step(P, W, o, d, S, n_box)) {}
     } else {
-        while (sah_step(P, W, o, d, tmin, stack, stride, n_box, n_tri)) {}
+        while (sah_step(P, W, o, d, tmin, S, n_box, n_tri)) {}
     }
     return sah_hit(P, W, o, d);
 }

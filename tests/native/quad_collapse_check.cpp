@@ -171,7 +171,32 @@ int main(int argc, char **argv)
         const bool same = best == best_brute || (best >= 0 && best_brute >= 0 && std::fabs(tbest - t_brute) <= 1e-6f * std::fabs(t_brute));
         if (!same) { printf("ray %d: walk found slot %d (t %g), brute force %d (t %g)\n", r, best, tbest, best_brute, t_brute); return 1; }
     }
-    printf("ok: %zu triangles, %zu pairs -> %zu quads, stack bound %u (pair form %u), deepest in %d rays %u, %.1f visits per ray\n",
-           n, b.pairs.size(), nq, bound, b.max_stack, rays, deepest, visits / rays);
+    // 3. the 64-byte form (quantise_sah_quads): same topology, every decoded child box CONTAINS the box it stands for (decoded
+    //    with the device's own expression, quadq_plane), and is not looser than two units per plane.
+    std::vector<QuadQ> qq;
+    if (!quantise_sah_quads(q, qq) || qq.size() != nq) { printf("quantise refused the tree\n"); return 1; }
+    double slack = 0.0, extent = 0.0;
+    for (size_t qi = 0; qi < nq; qi++) {
+        const Quad Q = quad_at(q, (uint32_t)qi);
+        const QuadQ &z = qq[qi];
+        const float org[3] = {z.ox, z.oy, z.oz};
+        const uint32_t ex[3] = {z.exps & 0xffu, (z.exps >> 8) & 0xffu, (z.exps >> 16) & 0xffu};
+        for (int i = 0; i < 4; i++) {
+            if (absent(Q.box[i])) { if (z.link[i] != kNone) { printf("absent child with a link in the 64-byte form\n"); return 1; } continue; }
+            const uint32_t want = (Q.link[i] & 15u) ? Q.link[i] : Q.link[i] / 2u;
+            if (z.link[i] != want) { printf("quad %zu child %d: link %u, expected %u\n", qi, i, z.link[i], want); return 1; }
+            const uint32_t by[6] = {z.lo[i] & 0xffu, z.lo[i] >> 24, (z.lo[i] >> 8) & 0xffu, z.hi[i] & 0xffu, (z.lo[i] >> 16) & 0xffu, (z.hi[i] >> 8) & 0xffu};
+            for (int a = 0; a < 3; a++) {
+                const float lo = quadq_plane(by[2 * a], ex[a], org[a]), hi = quadq_plane(by[2 * a + 1], ex[a], org[a]);
+                union { uint32_t u; float f; } unit; unit.u = ex[a] << 23;
+                if (!(lo <= Q.box[i][2 * a]) || !(hi >= Q.box[i][2 * a + 1])) { printf("quad %zu child %d axis %d: decoded [%g, %g] does not contain [%g, %g]\n", qi, i, a, lo, hi, Q.box[i][2 * a], Q.box[i][2 * a + 1]); return 1; }
+                if (Q.box[i][2 * a] - lo > 2.0f * unit.f + 1e-6f * std::fabs(lo) || hi - Q.box[i][2 * a + 1] > 2.0f * unit.f + 1e-6f * std::fabs(hi)) { printf("quad %zu child %d axis %d: looser than two units\n", qi, i, a); return 1; }
+                slack += (Q.box[i][2 * a] - lo) + (hi - Q.box[i][2 * a + 1]);
+                extent += Q.box[i][2 * a + 1] - Q.box[i][2 * a];
+            }
+        }
+    }
+    printf("ok: %zu triangles, %zu pairs -> %zu quads, stack bound %u (pair form %u), deepest in %d rays %u, %.1f visits per ray; 64-byte form adds %.2f %% to the boxes' extents\n",
+           n, b.pairs.size(), nq, bound, b.max_stack, rays, deepest, visits / rays, extent > 0 ? 100.0 * slack / extent : 0.0);
     return 0;
 }

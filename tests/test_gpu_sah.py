@@ -12,6 +12,13 @@ from conftest import BOX_CAMERA, DUCK_CAMERA
 pytestmark = pytest.mark.gpu
 
 
+def _set_form(monkeypatch, wide):
+    """Device form of the SAH tree: 0 = NodePair records, 1 = 4-wide nodes of 128 bytes (the default for cache-resident
+    trees), 2 = 4-wide nodes of 64 bytes with 8-bit child planes rounded outwards (the default beyond 64 MB)."""
+    monkeypatch.setenv("PTAMD_SAH_WIDE", "0" if wide == 0 else "1")
+    monkeypatch.setenv("PTAMD_SAH_QUANT", "1" if wide == 2 else "0")
+
+
 def _tracer(pt, scene, cam, W=8, H=8, spp=1, depth=1, sah=True):
     fb = pt.Framebuffer(pt.Resolution(W, H))
     tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, pt.CameraConfig(cam[0], cam[1]))
@@ -20,13 +27,14 @@ def _tracer(pt, scene, cam, W=8, H=8, spp=1, depth=1, sah=True):
     return tr, fb
 
 
-@pytest.mark.parametrize("name,n,wide", [("box", 10_000_000, 1), ("duck", 10_000_000, 1), ("box", 4_000_000, 0), ("duck", 4_000_000, 0)])
+@pytest.mark.parametrize("name,n,wide", [("box", 10_000_000, 1), ("duck", 10_000_000, 1), ("box", 4_000_000, 0), ("duck", 4_000_000, 0),
+                                         ("box", 10_000_000, 2), ("duck", 10_000_000, 2)])
 def test_sah_closest_hits_equal_reference_traversal(pt, box_scene, duck_scene, gpu_device, monkeypatch, name, n, wide):
     """SURVEY 8f-1 parity gate: identical closest-hit triangle and t as the reference-topology walk on
     1e7 random rays (origins inside the scene's bounds, every 13th direction in a coordinate plane).
     Both walks run on the GPU; ties resolve by the reference's visit order in both.  wide = 1: the tree in its 4-wide
     device form (the default); 0: the pair form (PTAMD_SAH_WIDE=0)."""
-    monkeypatch.setenv("PTAMD_SAH_WIDE", str(wide))
+    _set_form(monkeypatch, wide)
     scene, cam = (box_scene, BOX_CAMERA) if name == "box" else (duck_scene, DUCK_CAMERA)
     rng = np.random.default_rng(11)
     tris = scene.triangles
@@ -52,7 +60,7 @@ def test_sah_closest_hits_equal_reference_traversal(pt, box_scene, duck_scene, g
     assert hits > n // 2
 
 
-@pytest.mark.parametrize("name,parts,wide", [("box", 16, 1), ("box", 64, 1), ("duck", 16, 1), ("duck", 4, 0)])
+@pytest.mark.parametrize("name,parts,wide", [("box", 16, 1), ("box", 64, 1), ("duck", 16, 1), ("duck", 4, 0), ("duck", 16, 2)])
 def test_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, duck_oracle, gpu_device, monkeypatch, name, parts, wide):
     """The SAH kernel hands its critically dear tiles to several waves (a few pixels each) from the second launch of a
     rectangle on: which wave renders a pixel must never change it.  PTAMD_SPLIT_PCT = 10 makes every launch's dearest
@@ -60,7 +68,7 @@ def test_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, 
     same counters (box / triangle tests included: per pixel the walk is the same)."""
     monkeypatch.setenv("PTAMD_SPLIT_PCT", "10")
     monkeypatch.setenv("PTAMD_SAH_SPLIT", str(parts))
-    monkeypatch.setenv("PTAMD_SAH_WIDE", str(wide))
+    _set_form(monkeypatch, wide)
     scene, cam, oracle = (box_scene, BOX_CAMERA, box_oracle) if name == "box" else (duck_scene, DUCK_CAMERA, duck_oracle)
     W, H, spp, depth = 200, 168, 3, 5               # 25 x 21 tiles: enough workgroups for a cost-ordered schedule
     tr, fb = _tracer(pt, scene, cam, W, H, spp, depth, sah=True)
@@ -84,11 +92,11 @@ def test_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, 
     tr.close()
 
 
-@pytest.mark.parametrize("wide", [1, 0])
+@pytest.mark.parametrize("wide", [1, 0, 2])
 @pytest.mark.parametrize("name,W,H,spp,depth", [("box", 160, 90, 8, 8), ("duck", 96, 54, 3, 8)])
 def test_sah_images_match_oracle(pt, box_scene, duck_scene, gpu_device, monkeypatch, name, W, H, spp, depth, wide):
     import os
-    monkeypatch.setenv("PTAMD_SAH_WIDE", str(wide))
+    _set_form(monkeypatch, wide)
     from conftest import ROOT
     g = np.load(os.path.join(ROOT, "tests", "golden", "%s_%dx%d_%dspp_%db.npz" % (name, W, H, spp, depth)))
     scene, cam = (box_scene, BOX_CAMERA) if name == "box" else (duck_scene, DUCK_CAMERA)
@@ -107,6 +115,36 @@ def test_sah_images_match_oracle(pt, box_scene, duck_scene, gpu_device, monkeypa
     assert cnt["tri_tests"] < int(g["counters"][3])        # and it is less work
     if name == "duck":
         assert cnt["tri_tests"] * 20 < int(g["counters"][3])
+
+
+@pytest.mark.parametrize("wide", [1, 0, 2])
+def test_sah_stack_overflow_area_never_changes_a_byte(pt, duck_scene, gpu_device, monkeypatch, wide):
+    """The persistent SAH kernel keeps the top 16 entries of every lane's stack in LDS and moves deeper ones, eight at a
+    time, to device memory (SahStack).  Forced to 11 entries, rays spill all the time: frames and EVERY counter (the walk
+    itself is unchanged) must equal the whole-stack-in-LDS run, on the duck and on a 524 k-triangle terrain; debug counter
+    5 proves that the overflow path ran (and that it did not in the control)."""
+    import ctypes as C
+    _set_form(monkeypatch, wide)
+    terr = pt.make_terrain_scene(512)
+    cases = [(duck_scene, DUCK_CAMERA, 320, 180, 4, 8), (terr, ((0.0, 220.0, 620.0), (0.0, -0.35, -1.0), 45.0, 45.0), 480, 272, 4, 8)]
+    for scene, cam, W, H, spp, depth in cases:
+        out = {}
+        for cap in (0, 11, 16):
+            monkeypatch.setenv("PTAMD_SAH_STACK", str(cap))
+            tr, fb = _tracer(pt, scene, cam, W, H, spp, depth, sah=True)
+            tr.resetCounters()
+            for _ in range(2):                                  # second launch: cost-ordered schedule, split tiles
+                tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+            raw = (C.c_uint64 * 8)()
+            pt.capi.check(pt.capi.lib().pt_debug_counters_read(tr._h, raw))
+            out[cap] = (fb.rgb_host().copy(), fb.yuv_host().copy(), tr.readCounters(), int(raw[5]))
+            tr.close()
+        assert out[0][3] == 0                                   # the whole stack in LDS: nothing ever spills
+        if wide:                                                # (the pair form's bound on these trees may fit 11 entries: nothing to spill)
+            assert out[11][3] > 0, "the forced-short stack never overflowed: the test does not test"
+        for cap in (11, 16):
+            assert np.array_equal(out[cap][0], out[0][0]) and np.array_equal(out[cap][1], out[0][1]) and out[cap][2] == out[0][2], cap
+        print("spilled blocks at 11 / 16 entries:", out[11][3], out[16][3], "of", out[0][2]["box_tests"] // 4, "node visits")
 
 
 def test_sah_handles_tiny_and_terrain_scenes(pt, ob, gpu_device):

@@ -66,6 +66,8 @@ def one(seed):
     os.environ["PTAMD_SPLIT_PCT"] = str(int(rng.choice([10, 90])))
     os.environ["PTAMD_SAH_SPLIT"] = str(int(rng.choice([0, 4, 16, 64])))
     os.environ["PTAMD_SAH_WIDE"] = str(int(rng.choice([0, 1, 1])))          # the SAH tree's device form: pairs or 4-wide nodes
+    os.environ["PTAMD_SAH_QUANT"] = str(int(rng.choice([0, 1])))            # ... in 128-byte or in 64-byte (quantised) records
+    os.environ["PTAMD_SAH_STACK"] = str(int(rng.choice([0, 11, 16])))       # ... with the whole stack in LDS or a short one + overflow area
     fb = pt.Framebuffer(pt.Resolution(W, H))
     tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, pt.CameraConfig(cam[0], cam[1], cam[2], cam[3]),
                              legacyMaterials=legacy, spheres=spheres)
