@@ -181,14 +181,31 @@ __device__ __forceinline__ void render_dealt_body(const RenderParams &P, const W
                 }
             }
             bool trace = alive;
+#ifdef PT_STAMPS
+            // diagnostic build only (tools/stamps.sh): shader-clock cycles of the three parts of a trip, summed per wave
+            // into counters[5..7] = {path start, walk, shading}; never compiled into the shipped library
+            const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
             if (alive && L.need_new && !start_path(L, P, x, y)) { alive = false; trace = false; }
+#ifdef PT_STAMPS
+            const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
             const unsigned long long trace_mask = pt_ballot(trace);
             if (trace_mask != 0ull) {                          // (the last trip of a wave only discovers that every pixel is done)
                 wave_seg += (uint32_t)__popcll(trace_mask);
                 trips++;
             }
             const Hit h = Wk.hit(P, lane, trace, L.ro, L.rd, wave_box, wave_tri);
+#ifdef PT_STAMPS
+            const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
             if (trace) Wk.shade_hit(L, P, h);
+#ifdef PT_STAMPS
+            {
+                const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+                if (lane == 0) { atomicAdd(&P.counters[5], st1 - st0); atomicAdd(&P.counters[6], st2 - st1); atomicAdd(&P.counters[7], st3 - st2); }
+            }
+#endif
         }
         KernargParams &E = *fresh_kernarg();
         if (in_frame) write_pixel(E, L.col, pixel_index);

@@ -379,7 +379,8 @@ class DevicePathTracer:
         """Raw counter words 5..7 (diagnostic PT_STAMPS build only)."""
         raw = (C.c_uint64 * 8)()
         capi.check(capi.lib().pt_debug_counters_read(self._h, raw))
-        return {"longest_wave_cycles": int(raw[5]), "sum_traversal_cycles": int(raw[6]), "sum_wave_cycles": int(raw[7])}
+        return {"longest_wave_cycles": int(raw[5]), "sum_traversal_cycles": int(raw[6]), "sum_wave_cycles": int(raw[7]),
+                "raw": [int(v) for v in raw]}
 
     def resetCounters(self):
         capi.check(capi.lib().pt_counters_reset(self._h))
