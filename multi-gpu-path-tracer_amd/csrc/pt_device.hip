@@ -519,161 +519,6 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
     }
 }
 
-// The same kernel with lanes that RUN AHEAD.  In render_sah_body a lane whose pixel is finished idles until the last pixel of
-// the wave's tile is: on the 8 M-triangle terrain that is 22 % of all lane slots of the micro-step trips (12 % on the duck;
-// tools/occupancy_census.sh, profiles/r03_sah_lane_census.json), because a tile's pixels differ several-fold in cost, and the
-// 60 idle lanes of a 4-pixel part of a split tile are idle for good.  Here a wave holds up to two slots of the launch's order
-// at once (generations g and g + 1): a lane that finishes its pixel of generation g takes its pixel of generation g + 1 at
-// once, the wave draws generation g + 2 when the last lane has left g.  Two clusters of rays per wave instead of one keep
-// most of the coherence that a per-lane pixel queue over the whole launch loses (branch sah-pixel-queue-experiment:
-// -20 % on whole frames).  Which lane of which wave renders a pixel never changes its value (per-pixel RNG streams), counters
-// are per-ray sums: bytes and counters equal render_sah_body's.
-template <int kForm>
-__device__ __forceinline__ void render_sah_ahead_body(const RenderParams &P)
-{
-    extern __shared__ float4 lds_raw[];
-    const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
-    const ShadeView V = stage_shade(P, LL.tail, tid, kBlock);
-    const SahStack stack = {LL.stack + tid, kBlock, P.stack_cap,
-                            P.stack_spill ? P.stack_spill + ((size_t)(blockIdx.x * kWavesPerBlock + (tid >> 6)) * (size_t)P.spill_blocks * 64 + (size_t)lane) * kSpillBlock
-                                          : nullptr,
-                            P.counters + 5};
-    const uint32_t parts = (uint32_t)P.split_parts;
-    uint32_t n_split = 0, n_slots_all = 0;
-    {
-        KernargParams &K = *fresh_kernarg();
-        if (K.n_split) n_split = K.n_split[0];
-        n_slots_all = K.n_slots + n_split * (parts - 1u);
-    }
-    // wave-uniform: the two generations in flight (slot of the launch's order, cost counter at its claim), oldest and newest
-    uint32_t slot0 = 0, slot1 = 0, born0 = 0, born1 = 0;
-    int gen_lo = 0, gen_hi = -1;
-    bool exhausted = false;
-    // per lane: generation of its current (or last) pixel, its frame coordinates, the path and walk state
-    int gen = -1, x = 0, y = 0;
-    bool alive = false;                                       // has an unfinished pixel
-    PathState L;
-    path_init(L, P, 0);
-    SahWalk W;
-    sah_begin(W, mk3(1.0f, 1.0f, 1.0f), 0.0f);
-    W.pair = kNoPair;
-    uint32_t cost = 0, wave_seg = 0;
-#ifdef PT_OCC
-    unsigned long long occ[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    // (One back edge, one exit, no `continue`: every extra edge makes hipcc keep another copy of the path state in registers.)
-    bool run = true;
-    while (run) {
-        // 1. pixels whose samples are all done leave: store, free the lane
-        if (alive && !sah_walking(W) && L.need_new && L.s >= P.spp) {
-            KernargParams &E = *fresh_kernarg();
-            write_pixel(E, L.col, (E.H - y - 1) * E.W + x);
-            alive = false;
-        }
-        // 2. retire generations every lane has left, hand the free lanes their pixel of the next generation, draw a new
-        //    generation when the free lanes have nowhere to go and fewer than two are in flight; until nothing moves
-        bool moved = pt_ballot(!alive & !sah_walking(W)) != 0ull;      // nobody free: nothing to do
-        while (moved) {
-            moved = false;
-            while (gen_lo <= gen_hi && pt_ballot((gen < gen_lo) | ((gen == gen_lo) & (alive | sah_walking(W)))) == 0ull) {
-                KernargParams &E = *fresh_kernarg();
-                const uint32_t slot = (gen_lo & 1) ? slot1 : slot0, born = (gen_lo & 1) ? born1 : born0;
-                if (E.tile_cost && lane == 0) {
-                    const bool is_part = slot < n_split * parts;
-                    const uint32_t entry = is_part ? slot / parts : slot - n_split * (parts - 1u);
-                    const uint32_t tile = E.tile_order ? E.tile_order[entry] : entry;
-                    const uint32_t c = cost - born;
-                    // a part stands for its tile with the longest part's cost, scaled to what the whole tile would have cost
-                    if (is_part) atomicMax(&E.tile_cost[tile], c + c / 4u);
-                    else E.tile_cost[tile] = c;
-                }
-                gen_lo++;
-                moved = true;
-            }
-            const bool is_free = !alive & !sah_walking(W);
-            const unsigned long long movers = pt_ballot(is_free & (gen < gen_hi));
-            moved = moved || movers != 0ull;
-            if (pt_ballot(is_free) != 0ull && movers == 0ull && !exhausted && gen_hi - gen_lo + 1 < 2) {
-                // every free lane has done its pixel of the newest generation, and there is room for another
-                KernargParams &K = *fresh_kernarg();
-                uint32_t slot = 0;
-                if (lane == 0) slot = atomicAdd(K.tile_next, 1u);
-                slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-                if (slot >= n_slots_all) exhausted = true;             // the counter only grows: every later draw fails as well
-                else {
-                    gen_hi++;
-                    if (gen_hi & 1) { slot1 = slot; born1 = cost; } else { slot0 = slot; born0 = cost; }
-                    moved = true;
-                }
-            }
-            if (is_free & (gen < gen_hi)) {
-                gen++;
-                KernargParams &K = *fresh_kernarg();
-                const SlotWork sw = slot_work(K, (gen & 1) ? slot1 : slot0, n_split, parts, lane);
-                int pixel_index;
-                const bool in_frame = tile_pixel(K, sw.tile, sw.tile_lane, x, y, pixel_index) && sw.lane_on;
-                pixel_init(L, P, pixel_index);
-                alive = in_frame && P.depth > 0;
-                if (in_frame && P.depth == 0) {               // depth 0: camera rays are generated, then ray_color returns untraced
-                    L.n_paths += (uint32_t)P.spp;
-                    write_pixel(K, L.col, pixel_index);
-                }
-            }
-        }
-        const bool any = pt_ballot(alive | sah_walking(W)) != 0ull;
-        if (any) {
-            // 3. the trip of render_sah_body
-            cost += 8;
-            fold_counters(L, P.fold_bits);
-#ifdef PT_OCC
-            occ[7]++; occ[5]++; occ[6] += (unsigned long long)pt_popc(pt_ballot(alive && !sah_walking(W)));
-#endif
-            bool begins = false;
-            if (alive && !sah_walking(W)) {
-                if (!L.need_new || start_path(L, P, x, y)) {      // (start_path cannot fail here: finished pixels left in step 1)
-                    begins = true;
-                    sah_begin(W, L.rd, 3.402823466e+38f);
-                }
-            }
-            wave_seg += (uint32_t)__builtin_popcountll(pt_ballot(begins));
-            const uint32_t total = (uint32_t)pt_popc(pt_ballot(W.n0 != 0) | pt_ballot(W.pair != kNoPair));
-            while (true) {
-                const unsigned long long tri_mask = pt_ballot(W.n0 != 0), pair_mask = pt_ballot(W.pair != kNoPair);
-                const uint32_t still = (uint32_t)pt_popc(tri_mask | pair_mask);
-                if (still * 100u <= total * (uint32_t)P.spec_pct) break;
-                const int want_tri = pt_popc(tri_mask), want_node = pt_popc(pair_mask & ~tri_mask);
-#ifdef PT_OCC
-                {
-                    const int run_ = want_tri >= want_node ? want_tri : want_node, lose = want_tri >= want_node ? want_node : want_tri;
-                    const int waiting = pt_popc(pt_ballot(alive) & ~(tri_mask | pair_mask));
-                    occ[0]++; occ[1] += (unsigned long long)run_; occ[2] += (unsigned long long)lose; occ[3] += (unsigned long long)waiting;
-                    occ[4] += (unsigned long long)(64 - run_ - lose - waiting);
-                }
-#endif
-                if (want_tri >= want_node) {
-                    if (sah_wants_tri(W)) (void)sahw_tri_step(P, W, L.ro, L.rd, 0.001f, stack, L.n_tri);
-                } else {
-                    if (sah_wants_node(W)) {
-                        if (kForm == 2) (void)sahq_node_step(P, W, L.ro, L.rd, stack, L.n_box);
-                        else (void)sahw_node_step(P, W, L.ro, L.rd, stack, L.n_box);
-                    }
-                }
-                cost++;
-            }
-            if (alive && !sah_walking(W)) shade(L, P, V, sah_hit(P, W, L.ro, L.rd));
-        }
-        run = any || !exhausted;
-    }
-    KernargParams &E = *fresh_kernarg();
-    L.n_seg = 0;
-#ifdef PT_OCC
-    if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_occ[k], occ[k]);
-#endif
-    flush_counters(E, L, lane, 0ull, 0ull, wave_seg);
-}
-
 // Two builds of the same body.  Its natural allocation is 93 VGPRs (5 waves/SIMD).  Scenes whose tree
 // and triangles stay in cache are issue-bound and gain from a sixth wave even at the price of a few
 // spills (C3 143 -> 136 ms); the 1 GB terrain is bound by memory latency per dependent step and loses
@@ -684,9 +529,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 __global__ __launch_bounds__(kBlock) void render_kernel_sahw(RenderParams P) { render_sah_body<1>(P); }
 // the 4-wide form in 64-byte records (RenderParams::sah == 3): trees beyond the caches
 __global__ __launch_bounds__(kBlock) void render_kernel_sahq(RenderParams P) { render_sah_body<2>(P); }
-// ... with lanes that run ahead into the wave's next slot (render_sah_ahead_body)
-__global__ __launch_bounds__(kBlock) void render_kernel_sahw_ahead(RenderParams P) { render_sah_ahead_body<1>(P); }
-__global__ __launch_bounds__(kBlock) void render_kernel_sahq_ahead(RenderParams P) { render_sah_ahead_body<2>(P); }
 
 // ---- known-answer kernels (bit-exactness contract) -----------------------------------
 __global__ void kat_arith_kernel(int op, const float *a, const float *b, float *o0, float *o1, size_t n)
@@ -950,7 +792,6 @@ struct pt_device {
     bool sah = false;             // uploaded with the opt-in SAH tree instead of the reference topology
     bool sah_wide = true;         // upload the SAH tree in its 4-wide form (PTAMD_SAH_WIDE=0: the pair form)
     bool sah_wide_on = false;     // ... and the uploaded scene has it
-    bool sah_ahead = true;        // persistent SAH kernel, 4-wide forms: lanes run ahead into the wave's next slot (PTAMD_SAH_AHEAD=0: one tile at a time)
     int sah_quant = -1;           // the 4-wide form in 64-byte records (QuadQ): -1 = for trees beyond 64 KB, 0 = never, 1 = always (PTAMD_SAH_QUANT)
     bool sah_quant_on = false;    // ... and the uploaded scene has it
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
@@ -1102,7 +943,6 @@ try {
     // out-of-range values are ignored
     if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;
     if (const char *e = getenv("PTAMD_SAH_WIDE")) d->sah_wide = atoi(e) != 0;
-    if (const char *e = getenv("PTAMD_SAH_AHEAD")) d->sah_ahead = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_SAH_QUANT")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->sah_quant = v; }
     if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 99) d->spec_pct = v; }   // 100 would leave the walk loop before its first step
     if (const char *e = getenv("PTAMD_DEAL")) d->deal_auto = atoi(e) != 0;
@@ -1650,8 +1490,8 @@ static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool 
         (void)scene_bytes;      // round 1 picked the 6-wave build for cache-resident scenes; after round 2's diet the natural
                                 // (5-wave, spill-free) build is as fast there (C3 132.9 vs 133.8 ms) and faster on C4
         const bool six = dev->sah_waves == 6;
-        if (dev->sah_quant_on) return dev->sah_ahead ? PT_KERNEL(dev::render_kernel_sahq_ahead) : PT_KERNEL(dev::render_kernel_sahq);
-        if (dev->sah_wide_on) return dev->sah_ahead ? PT_KERNEL(dev::render_kernel_sahw_ahead) : PT_KERNEL(dev::render_kernel_sahw);
+        if (dev->sah_quant_on) return PT_KERNEL(dev::render_kernel_sahq);
+        if (dev->sah_wide_on) return PT_KERNEL(dev::render_kernel_sahw);
         return six ? PT_KERNEL(dev::render_kernel_sah6) : PT_KERNEL(dev::render_kernel_sah);
     }
     if (walk == 3) return PT_KERNEL(dev::render_kernel<false, true, 3>);

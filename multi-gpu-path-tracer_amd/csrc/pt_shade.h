@@ -262,17 +262,6 @@ __device__ __forceinline__ void path_init(PathState &L, const RenderParams &P, i
     L.box_hi = L.tri_hi = 0;
 }
 
-// A lane of a persistent wave moves on to its next pixel: everything path_init sets except the work counters, which keep
-// running for the wave's whole life (render_sah_ahead_body).
-__device__ __forceinline__ void pixel_init(PathState &L, const RenderParams &P, int pixel_index)
-{
-    xorwow_init(L.rng, (uint64_t)(long long)(1984 + pixel_index));
-    L.col = mk3(0.0f, 0.0f, 0.0f);
-    L.atten = mk3(1.0f, 1.0f, 1.0f);
-    L.ro = P.cam.origin; L.rd = mk3(0.0f, 0.0f, 0.0f);
-    L.s = 0; L.bounce = 0; L.need_new = true;
-}
-
 // Starts the next sample of pixel (x, y): DevicePathTracer.h:84-86 + camera::get_ray camera.h:95-97.
 // Returns false when all samples are done.
 __device__ __forceinline__ bool start_path(PathState &L, const RenderParams &P, int x, int y)
