@@ -599,6 +599,40 @@ bool collapse_sah_quads(const SahBvh &in, std::vector<NodePair> &quads2, uint32_
     return c.ok && (quads2.size() / 2) * 128ull < (1ull << 32);
 }
 
+uint32_t sah_quads_top_levels_first(std::vector<NodePair> &quads2, uint32_t n_top)
+{
+    const uint32_t nq = (uint32_t)(quads2.size() / 2);
+    if (nq == 0 || n_top == 0) return 0;
+    std::vector<uint32_t> bfs;                              // old indices, breadth first, at most n_top
+    std::vector<uint8_t> taken(nq, 0);
+    bfs.push_back(0); taken[0] = 1;
+    for (size_t head = 0; head < bfs.size() && bfs.size() < n_top; head++) {
+        const NodePair &h0 = quads2[2 * (size_t)bfs[head]];
+        const float *box[4] = {&h0.lxmin, &h0.lxmin + 6, &quads2[2 * (size_t)bfs[head] + 1].lxmin, &quads2[2 * (size_t)bfs[head] + 1].lxmin + 6};
+        const uint32_t link[4] = {h0.llink, h0.lcnt, h0.rlink, h0.rcnt};
+        for (int c = 0; c < 4 && bfs.size() < n_top; c++) {
+            if (!(box[c][0] < INFINITY) || (link[c] & 15u)) continue;      // absent, or a leaf
+            const uint32_t q = link[c] / 128u;
+            if (q < nq && !taken[q]) { taken[q] = 1; bfs.push_back(q); }
+        }
+    }
+    std::vector<uint32_t> perm(nq);                         // old -> new
+    uint32_t next = 0;
+    for (uint32_t q : bfs) perm[q] = next++;
+    for (uint32_t q = 0; q < nq; q++) if (!taken[q]) perm[q] = next++;
+    std::vector<NodePair> out(quads2.size());
+    for (uint32_t q = 0; q < nq; q++) {
+        NodePair h0 = quads2[2 * (size_t)q], h1 = quads2[2 * (size_t)q + 1];
+        const float *box[4] = {&h0.lxmin, &h0.lxmin + 6, &h1.lxmin, &h1.lxmin + 6};
+        uint32_t *link[4] = {&h0.llink, &h0.lcnt, &h0.rlink, &h0.rcnt};
+        for (int c = 0; c < 4; c++)
+            if (box[c][0] < INFINITY && !(*link[c] & 15u)) *link[c] = perm[*link[c] / 128u] * 128u;
+        out[2 * (size_t)perm[q]] = h0; out[2 * (size_t)perm[q] + 1] = h1;
+    }
+    quads2.swap(out);
+    return (uint32_t)bfs.size();
+}
+
 bool quantise_sah_quads(const std::vector<NodePair> &quads2, std::vector<QuadQ> &out)
 {
     const size_t nq = quads2.size() / 2;

@@ -383,10 +383,17 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
                             P.stack_spill ? P.stack_spill + ((size_t)(blockIdx.x * kWavesPerBlock + (tid >> 6)) * (size_t)P.spill_blocks * 64 + (size_t)lane) * kSpillBlock
                                           : nullptr,
 #ifdef PT_STALE
-                            nullptr};                          // (that diagnostic build keeps its own figures in counters[5..6])
+                            nullptr,                           // (that diagnostic build keeps its own figures in counters[5..6])
 #else
-                            P.counters + 5};
+                            P.counters + 5,
 #endif
+                            V.end, (uint32_t)(P.top_records * P.top_record_bytes)};
+    if (P.top_records > 0) {                               // the tree's top levels, once per workgroup of the persistent launch
+        const float4 *gn = reinterpret_cast<const float4 *>(P.nodes);
+        const int n4 = P.top_records * (P.top_record_bytes / 16);
+        for (int i = tid; i < n4; i += kBlock) V.end[i] = gn[i];
+        __syncthreads();
+    }
     // Persistent waves, as in render_kernel_dealt: every wave takes its next tile from the launch's counter.
     // Split tiles.  A pixel's samples are one chain, and on a scene like C4's terrain the few dearest tiles (rays skimming
     // the ground towards the horizon) cost five times the median: started first, they still end last, alone on the
@@ -792,7 +799,9 @@ struct pt_device {
     bool sah = false;             // uploaded with the opt-in SAH tree instead of the reference topology
     bool sah_wide = true;         // upload the SAH tree in its 4-wide form (PTAMD_SAH_WIDE=0: the pair form)
     bool sah_wide_on = false;     // ... and the uploaded scene has it
-    int sah_quant = -1;           // the 4-wide form in 64-byte records (QuadQ): -1 = for trees beyond 64 KB, 0 = never, 1 = always (PTAMD_SAH_QUANT)
+    int sah_top = 64;             // 4-wide forms: this many top-level records (breadth first) go first and are staged in LDS (PTAMD_SAH_TOP; 0 = none)
+    uint32_t sah_top_moved = 0;   // ... how many the uploaded scene has in front
+    int sah_quant = -1;           // the 4-wide form in 64-byte records (QuadQ): -1 = for trees beyond 64 MB, 0 = never, 1 = always (PTAMD_SAH_QUANT)
     bool sah_quant_on = false;    // ... and the uploaded scene has it
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
     int spec_pct = -1;            // ... and leaves the walk loop when <= this % of the walkers remain; -1 = by scene size (fill_params)
@@ -943,6 +952,7 @@ try {
     // out-of-range values are ignored
     if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;
     if (const char *e = getenv("PTAMD_SAH_WIDE")) d->sah_wide = atoi(e) != 0;
+    if (const char *e = getenv("PTAMD_SAH_TOP")) { const int v = atoi(e); if (v >= 0 && v <= 1024) d->sah_top = v; }
     if (const char *e = getenv("PTAMD_SAH_QUANT")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->sah_quant = v; }
     if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 99) d->spec_pct = v; }   // 100 would leave the walk loop before its first step
     if (const char *e = getenv("PTAMD_DEAL")) d->deal_auto = atoi(e) != 0;
@@ -1075,6 +1085,7 @@ try {
     }
     SahBvh sahbvh;
     bool sah_wide_on = false, sah_quant_on = false;
+    uint32_t sah_top_moved = 0;
     if (sah) {
         build_sah_bvh(pos.data(), n, sahbvh);
         if (sahbvh.max_stack > 64) return set_error(PT_ERR_STACK, "SAH tree deeper than 64 levels");
@@ -1148,13 +1159,15 @@ try {
         sah_wide_on = dev->sah_wide && collapse_sah_quads(sahbvh, pairs, wide_stack) && wide_stack <= 64;
         if (sah_wide_on) {
             sahbvh.max_stack = wide_stack;       // entries a walk of the 4-wide form can have pushed at once
-            // All but toy trees take the 4-wide form at half the bytes (QuadQ: 8-bit child planes, rounded outwards): a visit is
-            // four per-lane 16-byte requests instead of seven, and on the 8.4 M-triangle terrain the vector-memory path was 70 %
-            // busy serving them (profiles/r03_c4_memory_path.json).  The decode costs ~48 instructions per visit: with the short
-            // LDS stack's fifth workgroup per CU, C4 55.4 -> 51.7 ms, C3 122.4 -> 119.0 ms; the Cornell box through the SAH tree
-            // (9 nodes, all in the scalar / L1 caches, purely issue-bound) 75.6 -> 79.2 ms, hence the size rule.
+            sah_top_moved = dev->sah_top > 0 ? sah_quads_top_levels_first(pairs, (uint32_t)dev->sah_top) : 0u;
+            // Trees that do not fit the caches take the 4-wide form at half the bytes (QuadQ: 8-bit child planes, rounded
+            // outwards): a visit is four per-lane 16-byte requests instead of seven, and on the 8.4 M-triangle terrain the
+            // vector-memory path was 70 % busy serving them (profiles/r03_sah_lane_census.json).  The decode costs ~48
+            // instructions per visit.  With the short LDS stack's fifth workgroup per CU: C4 55.4 -> 51.7 ms.  Cache-resident
+            // trees keep the 128-byte form: with their top levels in LDS (below) it is the faster one there (C3 110 ms against
+            // 120 ms for the 64-byte form; the Cornell box through the SAH tree 74 against 79 ms).
             const size_t wide_bytes = pairs.size() * sizeof(NodePair) + n * sizeof(TriIsect);
-            if (dev->sah_quant == 1 || (dev->sah_quant < 0 && wide_bytes > ((size_t)64 << 10))) {
+            if (dev->sah_quant == 1 || (dev->sah_quant < 0 && wide_bytes > ((size_t)64 << 20))) {
                 std::vector<QuadQ> qq;
                 if (quantise_sah_quads(pairs, qq)) {
                     static_assert(sizeof(QuadQ) == sizeof(NodePair), "a QuadQ record travels as one NodePair-sized record");
@@ -1270,6 +1283,7 @@ try {
     dev->sah = sah;
     dev->sah_wide_on = sah && sah_wide_on;
     dev->sah_quant_on = sah && sah_wide_on && sah_quant_on;
+    dev->sah_top_moved = sah && sah_wide_on ? sah_top_moved : 0u;
     dev->sah_stack = sah ? sahbvh.max_stack : 0;
     if (sah && getenv("PTAMD_VERBOSE"))
         fprintf(stderr, "ptamd: SAH tree %zu pairs, %s form %zu records, walk stack %u entries\n", sahbvh.pairs.size(),
@@ -1383,6 +1397,7 @@ static size_t lds_bytes(const RenderParams &P, int block, bool stage)
     f4 += ((size_t)P.stack_entries * block + 3) / 4;
     f4 += ((size_t)P.queue_entries * block * P.queue_dwords + 3) / 4;
     if (P.shade_lds) f4 += (P.shade_lds == 1 ? (size_t)P.n_tris * 3 : 0) + (size_t)P.n_mats * 3 + (size_t)P.n_lights * 5;
+    f4 += (size_t)P.top_records * (size_t)(P.top_record_bytes / 16);
     if (P.deal_cap > 0 && P.stack_entries == 0)       // dev::deal_carve (kWalk 4: no stack)
         f4 += (size_t)P.n_tris * 3 /* onb table, stage_shade_lds */ + (size_t)P.n_tris * 3 +
               (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 2 + 15) / 16);
@@ -1420,6 +1435,7 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.legacy_mats = dev->d_legacy; P.spheres = dev->d_spheres; P.n_spheres = dev->n_spheres;
     // SAH walks check for room before they push (SahStack): with the whole stack in LDS the check must never fire, hence + 3
     P.stack_spill = nullptr; P.spill_blocks = 0; P.stack_cap = 0x3fffffff;      // whole stack in LDS: the check never fires
+    P.top_records = 0; P.top_record_bytes = 64;
     if (dev->sah) P.stack_entries = (int)dev->sah_stack;
     P.queue_dwords = (dev->packed_queue && !dev->legacy_on) ? 1 : 2;      // the extension kernel uses the unpacked queue
     P.n_mats = (int)dev->n_mats;
@@ -1558,6 +1574,14 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         // bound of a deep tree (C4: 37 entries = 38 KB per workgroup) would otherwise cap its occupancy.
         P.stack_entries = P.stack_cap = dev->sah_stack_lds;
         P.spill_blocks = ((int)dev->sah_stack + 3 - dev->sah_stack_lds + dev::kSpillBlock - 1) / dev::kSpillBlock + 1;
+    }
+    if (walk == 3 && dev->sah_persistent && dev->sah_wide_on && dev->sah_top_moved > 0) {
+        // The tree's top levels in LDS (north_star's wording): every ray visits the root and its children, and a visit served
+        // from LDS returns in ~64 cycles instead of an L1 / L2 round trip -- two of the duck's 5.2 visits per segment.
+        // C3 123.7 -> 110.2 ms with 8 .. 96 records (profiles/r03_topk_lds.json); C4 (14.5 visits per segment, bound by the
+        // request path rather than by latency) 52.8 -> 52.4 ms; 256 records cost a resident workgroup and lose.
+        P.top_records = (int)dev->sah_top_moved;
+        P.top_record_bytes = dev->sah_quant_on ? 64 : 128;
     }
     const size_t lds = lds_bytes(P, dev::kBlock, stage);
     const KernelChoice choice = pick_kernel(dev, walk, coop, stage, packed);

@@ -111,6 +111,11 @@ void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out);
 // builder only makes at its depth limit).  max_stack = the most entries a walk can have pushed at once.
 bool collapse_sah_quads(const SahBvh &in, std::vector<NodePair> &quads2, uint32_t &max_stack);
 
+// Moves the first n_top nodes of a breadth-first walk from the root to the front of the array (the rest keep their order)
+// and rewrites the links: records [0, n_top) are then the TOP LEVELS of the tree, which the persistent SAH kernel can stage
+// in LDS (PTAMD_SAH_TOP; north_star: "top BVH levels ... staged in LDS").  Returns how many it moved (fewer for small trees).
+uint32_t sah_quads_top_levels_first(std::vector<NodePair> &quads2, uint32_t n_top);
+
 // The 4-wide form at HALF the bytes, for trees that do not fit the caches (C4: the walk is then bound by the number of
 // per-lane 16-byte requests the vector-memory path serves, profiles/r03_c4_memory_path.json): 64 B = four dwordx4 loads
 // instead of seven.  The four child boxes are 8-bit offsets from the node's origin in power-of-two units per axis:

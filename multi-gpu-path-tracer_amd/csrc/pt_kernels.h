@@ -47,6 +47,8 @@ struct RenderParams {
     int stack_cap;                    // SAH walks: entries a lane may hold in LDS before it spills (SahStack::cap); huge when everything fits
     uint32_t *stack_spill;            // persistent SAH kernel: where stacks deeper than stack_entries continue (SahStack), or null
     int spill_blocks;                 // ... blocks of 8 entries per lane in it
+    int top_records;                  // persistent SAH kernel: the first records of `nodes` (the tree's top levels) staged in LDS, or 0
+    int top_record_bytes;             // ... 64 or 128 bytes each
     int queue_entries;                // per-lane LDS leaf-queue slots (>= 2; 0 for the wave-uniform walks)
     int queue_dwords;                 // dwords per queue entry (1 packed, 2 otherwise)
     int n_pairs, n_tris;              // array lengths (for LDS staging)

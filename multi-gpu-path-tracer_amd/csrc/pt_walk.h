@@ -696,7 +696,14 @@ struct SahStack {
     int cap;                      // entries per lane in LDS
     uint32_t *spill;              // this lane's first block in device memory (block b at spill + b * 64 * 8 dwords), or null
     unsigned long long *n_spills; // counts blocks moved out (counters[5], read by pt_debug_counters_read: tests prove the path ran), or null
+    // the tree's top levels in LDS (PTAMD_SAH_TOP, default 64 records): records at byte offsets below top_bytes are read from
+    // `top` instead of from memory.  profiles/r03_topk_lds.json
+    const float4 *top;
+    uint32_t top_bytes;
 };
+// A node record's k-th float4: from the workgroup's LDS copy of the top levels, or from memory.
+#define PT_NODE_F4(S, P, off, k) (((off) < (S).top_bytes) ? (S).top[(off) / 16u + (k)] \
+                                                        : reinterpret_cast<const float4 *>(reinterpret_cast<const char *>((P).nodes) + (size_t)(off))[k])
 constexpr int kSpillBlock = 8;
 
 // Makes room for n more pushes (n <= 3 < kSpillBlock <= cap / 2).
@@ -894,8 +901,15 @@ __device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W
     uint32_t *const stack = S.lds;
     const int stride = S.stride;
     sah_stack_reserve(S, W, 3);
-    const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
-    const float4 q0 = np[0], q1 = np[1], q2 = np[2], lk = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
+    float4 q0, q1, q2, lk, q4, q5, q6;
+    if (S.top_bytes == 0u) {
+        const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
+        q0 = np[0]; q1 = np[1]; q2 = np[2]; lk = np[3]; q4 = np[4]; q5 = np[5]; q6 = np[6];
+    } else {
+        const uint32_t off = W.pair;
+        q0 = PT_NODE_F4(S, P, off, 0); q1 = PT_NODE_F4(S, P, off, 1); q2 = PT_NODE_F4(S, P, off, 2); lk = PT_NODE_F4(S, P, off, 3);
+        q4 = PT_NODE_F4(S, P, off, 4); q5 = PT_NODE_F4(S, P, off, 5); q6 = PT_NODE_F4(S, P, off, 6);
+    }
     const v3 inv = W.inv;
     float k0, k1, k2, k3;
     sahw_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, W.tbest, k0);
@@ -939,8 +953,14 @@ __device__ __forceinline__ bool sahq_node_step(const RenderParams &P, SahWalk &W
     uint32_t *const stack = S.lds;
     const int stride = S.stride;
     sah_stack_reserve(S, W, 3);
-    const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
-    const float4 q0 = np[0], q1 = np[1], q2 = np[2], lk = np[3];
+    float4 q0, q1, q2, lk;
+    if (S.top_bytes == 0u) {
+        const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
+        q0 = np[0]; q1 = np[1]; q2 = np[2]; lk = np[3];
+    } else {
+        const uint32_t off = W.pair;
+        q0 = PT_NODE_F4(S, P, off, 0); q1 = PT_NODE_F4(S, P, off, 1); q2 = PT_NODE_F4(S, P, off, 2); lk = PT_NODE_F4(S, P, off, 3);
+    }
     const uint32_t exps = __float_as_uint(q0.w);
     const float sx = __uint_as_float((exps & 0xffu) << 23), sy = __uint_as_float(((exps >> 8) & 0xffu) << 23), sz = __uint_as_float(((exps >> 16) & 0xffu) << 23);
     uint32_t l0 = __float_as_uint(lk.x), l1 = __float_as_uint(lk.y), l2 = __float_as_uint(lk.z), l3 = __float_as_uint(lk.w);
@@ -992,7 +1012,7 @@ __device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, f
 {
     SahWalk W;
     sah_begin(W, d, tmax0);
-    const SahStack S = {stack, stride, P.stack_cap, nullptr, nullptr};      // the whole stack in LDS: stack_cap is out of reach
+    const SahStack S = {stack, stride, P.stack_cap, nullptr, nullptr, nullptr, 0u};      // the whole stack in LDS: stack_cap is out of reach
     if (P.sah == 3) {
         while (W.n0 != 0 ? sahw_tri_step(P, W, o, d, tmin, S, n_tri) : sahq_node_step(P, W, o, d, S, n_box)) {}
     } else if (P.sah == 2) {

@@ -79,6 +79,21 @@ int main(int argc, char **argv)
     uint32_t bound = 0;
     if (!collapse_sah_quads(b, q, bound)) { printf("collapse refused the tree\n"); return 1; }
     const size_t nq = q.size() / 2;
+    // optional third argument: move that many top-level records (breadth first) to the front (sah_quads_top_levels_first, the
+    // layout of the PTAMD_SAH_TOP option) -- every check below must hold for the renumbered tree as well
+    if (argc > 3) {
+        const uint32_t want = (uint32_t)atol(argv[3]);
+        const uint32_t moved = sah_quads_top_levels_first(q, want);
+        if (moved > want || moved > nq || (nq >= want && moved != want)) { printf("top-levels-first moved %u of %u asked (%zu quads)\n", moved, want, nq); return 1; }
+        // the root stays the root; every record of the prefix but the root is the child of an EARLIER record (breadth first)
+        std::vector<int> reach(nq, 0);
+        reach[0] = 1;
+        for (uint32_t i = 0; i < moved; i++) {
+            if (!reach[i]) { printf("top-levels-first: record %u of the prefix is not below an earlier one\n", i); return 1; }
+            const Quad Q = quad_at(q, i);
+            for (int c = 0; c < 4; c++) if (!absent(Q.box[c]) && !(Q.link[c] & 15u) && Q.link[c] / 128u < nq) reach[Q.link[c] / 128u] = 1;
+        }
+    }
 
     // 1. structure
     std::vector<int> slot_seen(n, 0), quad_seen(nq, 0);

@@ -147,6 +147,28 @@ def test_sah_stack_overflow_area_never_changes_a_byte(pt, duck_scene, gpu_device
         print("spilled blocks at 11 / 16 entries:", out[11][3], out[16][3], "of", out[0][2]["box_tests"] // 4, "node visits")
 
 
+@pytest.mark.parametrize("wide", [1, 2])
+def test_sah_top_levels_in_lds_never_change_a_byte(pt, duck_scene, gpu_device, monkeypatch, wide):
+    """PTAMD_SAH_TOP (default 64; north_star's "top BVH levels staged in LDS"): the first N records of a breadth-first
+    renumbering are read from the workgroup's LDS copy instead of from memory.  Same tree, same walk: frames and every
+    counter must equal the run without it."""
+    _set_form(monkeypatch, wide)
+    terr = pt.make_terrain_scene(256)
+    cases = [(duck_scene, DUCK_CAMERA, 320, 180, 4, 8), (terr, ((0.0, 220.0, 620.0), (0.0, -0.35, -1.0), 45.0, 45.0), 320, 180, 4, 8)]
+    for scene, cam, W, H, spp, depth in cases:
+        out = {}
+        for top in (0, 1, 64, 200):
+            monkeypatch.setenv("PTAMD_SAH_TOP", str(top))
+            tr, fb = _tracer(pt, scene, cam, W, H, spp, depth, sah=True)
+            tr.resetCounters()
+            for _ in range(2):
+                tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+            out[top] = (fb.rgb_host().copy(), fb.yuv_host().copy(), tr.readCounters())
+            tr.close()
+        for top in (1, 64, 200):
+            assert np.array_equal(out[top][0], out[0][0]) and np.array_equal(out[top][1], out[0][1]) and out[top][2] == out[0][2], top
+
+
 def test_sah_handles_tiny_and_terrain_scenes(pt, ob, gpu_device):
     terr = pt.make_terrain_scene(48)
     cam = ((0.0, 220.0, 620.0), (0.0, -0.35, -1.0), 45.0, 45.0)

@@ -591,6 +591,10 @@ def test_sah_tree_four_wide_device_form(tmp_path):
     for n, seed in ((1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (9, 6), (17, 7), (37, 8), (500, 9), (3000, 10), (40000, 11)):
         r = subprocess.run([exe, str(n), str(seed)], capture_output=True, text=True)
         assert r.returncode == 0 and r.stdout.startswith("ok:"), (n, seed, r.stdout, r.stderr)
+    # the same with the tree's top levels moved to the front (the layout behind PTAMD_SAH_TOP)
+    for n, seed, top in ((1, 1, 8), (9, 6, 2), (500, 9, 16), (3000, 10, 64), (40000, 11, 256)):
+        r = subprocess.run([exe, str(n), str(seed), str(top)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.startswith("ok:"), (n, seed, top, r.stdout, r.stderr)
 
 
 def test_missing_native_library_fails_loudly(pt, monkeypatch):
