@@ -369,8 +369,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
 __device__ unsigned long long g_occ[8];
 #endif
 
-// kForm: 0 = NodePair records, 1 = the 4-wide form (128-byte records), 2 = the 4-wide form in 64-byte records (QuadQ)
-template <int kForm>
+// kForm: 0 = NodePair records, 1 = the 4-wide form (128-byte records), 2 = the 4-wide form in 64-byte records (QuadQ).
+// kTop / kSpill (pt_walk.h): the tree's top levels in LDS and the short LDS stack with its overflow area, each compiled in
+// (1), compiled out (0) or decided per launch (2).  The kernels the library picks by itself are specialised -- a cache-resident
+// tree gets the top levels and whole stacks, a tree beyond the caches the short stack and no top levels -- because a lone
+// wave's chain of dependent micro-steps is what bounds a rank's share of a frame, and generality costs instructions in it
+// (an eighth of the duck's frame: 47.4 ms with everything decided at run time, 43.9 ms with round 2's kernel).
+template <int kForm, int kTop = 2, int kSpill = 2>
 __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 {
     extern __shared__ float4 lds_raw[];
@@ -388,7 +393,7 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
                             P.counters + 5,
 #endif
                             V.end, (uint32_t)(P.top_records * P.top_record_bytes)};
-    if (P.top_records > 0) {                               // the tree's top levels, once per workgroup of the persistent launch
+    if (kTop != 0 && P.top_records > 0) {                  // the tree's top levels, once per workgroup of the persistent launch
         const float4 *gn = reinterpret_cast<const float4 *>(P.nodes);
         const int n4 = P.top_records * (P.top_record_bytes / 16);
         for (int i = tid; i < n4; i += kBlock) V.end[i] = gn[i];
@@ -476,13 +481,13 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 #endif
                 if (want_tri >= want_node) {
                     if (sah_wants_tri(W)) {
-                        if (kForm != 0) (void)sahw_tri_step(P, W, L.ro, L.rd, 0.001f, stack, L.n_tri);
+                        if (kForm != 0) (void)sahw_tri_step<kSpill>(P, W, L.ro, L.rd, 0.001f, stack, L.n_tri);
                         else (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
                     }
                 } else {
                     if (sah_wants_node(W)) {
-                        if (kForm == 2) (void)sahq_node_step(P, W, L.ro, L.rd, stack, L.n_box);
-                        else if (kForm == 1) (void)sahw_node_step(P, W, L.ro, L.rd, stack, L.n_box);
+                        if (kForm == 2) (void)sahq_node_step<kTop, kSpill>(P, W, L.ro, L.rd, stack, L.n_box);
+                        else if (kForm == 1) (void)sahw_node_step<kTop, kSpill>(P, W, L.ro, L.rd, stack, L.n_box);
                         else (void)sah_node_step(P, W, L.ro, L.rd, stack, L.n_box);
                     }
                 }
@@ -532,10 +537,16 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 // to the spills (C4 84 -> 88 ms), so it keeps the natural allocation.
 __global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P) { render_sah_body<0>(P); }
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_sah6(RenderParams P) { render_sah_body<0>(P); }
-// the 4-wide form of the tree (RenderParams::sah == 2)
-__global__ __launch_bounds__(kBlock) void render_kernel_sahw(RenderParams P) { render_sah_body<1>(P); }
-// the 4-wide form in 64-byte records (RenderParams::sah == 3): trees beyond the caches
-__global__ __launch_bounds__(kBlock) void render_kernel_sahq(RenderParams P) { render_sah_body<2>(P); }
+// the 4-wide form of the tree (RenderParams::sah == 2), cache-resident trees: top levels in LDS, short stack (together they
+// leave room for five workgroups per CU: whole stacks + the top levels are 35 KB per workgroup on the duck, four per CU)
+__global__ __launch_bounds__(kBlock) void render_kernel_sahw(RenderParams P) { render_sah_body<1, 1, 1>(P); }
+// ... for launches with fewer tiles than the device has wave slots (a rank's share of a multi-GPU frame): nothing but the walk
+__global__ __launch_bounds__(kBlock) void render_kernel_sahw_lean(RenderParams P) { render_sah_body<1, 0, 0>(P); }
+// the 4-wide form in 64-byte records (RenderParams::sah == 3), trees beyond the caches: short LDS stack + overflow area
+__global__ __launch_bounds__(kBlock) void render_kernel_sahq(RenderParams P) { render_sah_body<2, 0, 1>(P); }
+// either form with both options decided per launch (PTAMD_SAH_TOP / PTAMD_SAH_STACK / PTAMD_SAH_QUANT set by hand, and the tests)
+__global__ __launch_bounds__(kBlock) void render_kernel_sahw_any(RenderParams P) { render_sah_body<1, 2, 2>(P); }
+__global__ __launch_bounds__(kBlock) void render_kernel_sahq_any(RenderParams P) { render_sah_body<2, 2, 2>(P); }
 
 // ---- known-answer kernels (bit-exactness contract) -----------------------------------
 __global__ void kat_arith_kernel(int op, const float *a, const float *b, float *o0, float *o1, size_t n)
@@ -801,6 +812,7 @@ struct pt_device {
     bool sah_wide_on = false;     // ... and the uploaded scene has it
     int sah_top = 64;             // 4-wide forms: this many top-level records (breadth first) go first and are staged in LDS (PTAMD_SAH_TOP; 0 = none)
     uint32_t sah_top_moved = 0;   // ... how many the uploaded scene has in front
+    bool sah_by_hand = false;     // PTAMD_SAH_TOP / PTAMD_SAH_STACK given: both options as asked, in the kernels that decide them per launch
     int sah_quant = -1;           // the 4-wide form in 64-byte records (QuadQ): -1 = for trees beyond 64 MB, 0 = never, 1 = always (PTAMD_SAH_QUANT)
     bool sah_quant_on = false;    // ... and the uploaded scene has it
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
@@ -952,7 +964,7 @@ try {
     // out-of-range values are ignored
     if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;
     if (const char *e = getenv("PTAMD_SAH_WIDE")) d->sah_wide = atoi(e) != 0;
-    if (const char *e = getenv("PTAMD_SAH_TOP")) { const int v = atoi(e); if (v >= 0 && v <= 1024) d->sah_top = v; }
+    if (const char *e = getenv("PTAMD_SAH_TOP")) { const int v = atoi(e); if (v >= 0 && v <= 1024) { d->sah_top = v; d->sah_by_hand = true; } }
     if (const char *e = getenv("PTAMD_SAH_QUANT")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->sah_quant = v; }
     if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 99) d->spec_pct = v; }   // 100 would leave the walk loop before its first step
     if (const char *e = getenv("PTAMD_DEAL")) d->deal_auto = atoi(e) != 0;
@@ -965,7 +977,7 @@ try {
     if (const char *e = getenv("PTAMD_SPLIT_PCT")) { const int v = atoi(e); if (v >= 10 && v <= 1000) d->split_pct = v; }
     if (const char *e = getenv("PTAMD_DEAL_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 2 || v == 4 || v == 8) d->deal_split = v; }
     if (const char *e = getenv("PTAMD_SAH_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) d->sah_split = v; }
-    if (const char *e = getenv("PTAMD_SAH_STACK")) { const int v = atoi(e); if (v == 0 || (v >= 11 && v <= 64)) d->sah_stack_lds = v; }
+    if (const char *e = getenv("PTAMD_SAH_STACK")) { const int v = atoi(e); if (v == 0 || (v >= 11 && v <= 64)) { d->sah_stack_lds = v; d->sah_by_hand = true; } }
     if (const char *e = getenv("PTAMD_RESIDENT")) { const int v = atoi(e); if (v >= 1 && v <= 16) d->resident_cap = v; }
     if (const char *e = getenv("PTAMD_FOLD_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 31) d->fold_bits = v; }
     if (const char *e = getenv("PTAMD_COOP")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->coop_mode = v; }
@@ -1499,15 +1511,16 @@ static TileSchedule *schedule_for(pt_device *dev, const RenderParams &P, unsigne
 typedef void (*RenderKernel)(RenderParams);
 struct KernelChoice { RenderKernel fn; const char *name; };
 #define PT_KERNEL(...) KernelChoice{__VA_ARGS__, "pt::" #__VA_ARGS__}
-static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool stage, bool packed)
+static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool stage, bool packed, bool lean = false)
 {
+    if (lean) return PT_KERNEL(dev::render_kernel_sahw_lean);
     if (walk == 3 && dev->sah_persistent) {
         const size_t scene_bytes = dev->n_pairs * sizeof(NodePair) + dev->n_tris * sizeof(TriIsect);
         (void)scene_bytes;      // round 1 picked the 6-wave build for cache-resident scenes; after round 2's diet the natural
                                 // (5-wave, spill-free) build is as fast there (C3 132.9 vs 133.8 ms) and faster on C4
         const bool six = dev->sah_waves == 6;
-        if (dev->sah_quant_on) return PT_KERNEL(dev::render_kernel_sahq);
-        if (dev->sah_wide_on) return PT_KERNEL(dev::render_kernel_sahw);
+        if (dev->sah_quant_on) return dev->sah_by_hand ? PT_KERNEL(dev::render_kernel_sahq_any) : PT_KERNEL(dev::render_kernel_sahq);
+        if (dev->sah_wide_on) return dev->sah_by_hand ? PT_KERNEL(dev::render_kernel_sahw_any) : PT_KERNEL(dev::render_kernel_sahw);
         return six ? PT_KERNEL(dev::render_kernel_sah6) : PT_KERNEL(dev::render_kernel_sah);
     }
     if (walk == 3) return PT_KERNEL(dev::render_kernel<false, true, 3>);
@@ -1569,13 +1582,27 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
                       (dev->coop_mode == 1 || (walk == 2 && dev->coop_mode < 0 && dev->bvh.max_leaf >= 64 &&
                                                tiles * dev::kWavesPerBlock <= 3ll * dev->max_waves));
     if (coop) { blocks = (unsigned)tiles; P.queue_entries = 10; P.queue_dwords = 1; P.deal_cap = 0; }   // LDS per thread: 2 x (float4 partial hit + visit rank)
-    if (walk == 3 && dev->sah_persistent && dev->sah_stack_lds > 0 && (int)dev->sah_stack > dev->sah_stack_lds) {
+    // The library's own choice.  Launches that fill the device are bound by throughput: short LDS stacks (a fifth workgroup
+    // per CU), and for cache-resident trees (128-byte nodes) the top levels in LDS.  A launch with fewer tiles than the device
+    // has wave slots (a rank's share of a multi-GPU frame) lasts as long as its dearest pixel's chain of dependent micro-steps,
+    // and there every instruction in the step counts: an eighth of the duck's frame takes 43.9 ms with the bare walk against
+    // 46.5 - 47.4 ms with the options in (while the whole frame takes 123 against 110 ms): such launches get the lean kernel.
+    // By hand (PTAMD_SAH_TOP / _STACK): both options as asked, always.
+    bool lean = false;
+    if (walk == 3 && dev->sah_persistent && dev->sah_wide_on && !dev->sah_quant_on && !dev->sah_by_hand) {
+        const size_t lds_lean = lds_bytes(P, dev::kBlock, stage);            // P still has whole stacks and no top levels here
+        const long long slots = (long long)dev->cu_count * resident_per_cu(dev, (const void *)dev::render_kernel_sahw_lean, lds_lean) * dev::kWavesPerBlock;
+        lean = tiles <= slots;
+    }
+    const bool short_stack = !lean;
+    const bool top_levels = !lean && (dev->sah_by_hand || !dev->sah_quant_on);
+    if (walk == 3 && dev->sah_persistent && short_stack && dev->sah_stack_lds > 0 && (int)dev->sah_stack > dev->sah_stack_lds) {
         // The persistent SAH kernel keeps only the top of every lane's stack in LDS (SahStack, pt_walk.h): the worst-case
         // bound of a deep tree (C4: 37 entries = 38 KB per workgroup) would otherwise cap its occupancy.
         P.stack_entries = P.stack_cap = dev->sah_stack_lds;
         P.spill_blocks = ((int)dev->sah_stack + 3 - dev->sah_stack_lds + dev::kSpillBlock - 1) / dev::kSpillBlock + 1;
     }
-    if (walk == 3 && dev->sah_persistent && dev->sah_wide_on && dev->sah_top_moved > 0) {
+    if (walk == 3 && dev->sah_persistent && dev->sah_wide_on && top_levels && dev->sah_top_moved > 0) {
         // The tree's top levels in LDS (north_star's wording): every ray visits the root and its children, and a visit served
         // from LDS returns in ~64 cycles instead of an L1 / L2 round trip -- two of the duck's 5.2 visits per segment.
         // C3 123.7 -> 110.2 ms with 8 .. 96 records (profiles/r03_topk_lds.json); C4 (14.5 visits per segment, bound by the
@@ -1584,7 +1611,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         P.top_record_bytes = dev->sah_quant_on ? 64 : 128;
     }
     const size_t lds = lds_bytes(P, dev::kBlock, stage);
-    const KernelChoice choice = pick_kernel(dev, walk, coop, stage, packed);
+    const KernelChoice choice = pick_kernel(dev, walk, coop, stage, packed, lean);
     const RenderKernel kern = choice.fn;
     {
         const pt_status st = ensure_lds(dev, (const void *)kern, lds);

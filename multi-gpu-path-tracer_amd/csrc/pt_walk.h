@@ -706,10 +706,14 @@ struct SahStack {
                                                         : reinterpret_cast<const float4 *>(reinterpret_cast<const char *>((P).nodes) + (size_t)(off))[k])
 constexpr int kSpillBlock = 8;
 
-// Makes room for n more pushes (n <= 3 < kSpillBlock <= cap / 2).
+// Makes room for n more pushes (n <= 3 < kSpillBlock <= cap / 2).  kSpill: 0 = the kernel keeps whole stacks in LDS (no code
+// at all: the chain of dependent steps of a lone wave is what bounds a rank's share of a frame, and every instruction in it
+// counts), 1 = it has the overflow area, 2 = decided per launch.
+template <int kSpill>
 __device__ __forceinline__ void sah_stack_reserve(const SahStack &S, SahWalk &W, int n)
 {
-    if (__builtin_expect(pt_ballot(W.sp + n > S.cap) != 0ull, 0)) {
+    if (kSpill == 0) return;
+    if ((kSpill == 1 || S.spill != nullptr) && __builtin_expect(pt_ballot(W.sp + n > S.cap) != 0ull, 0)) {
         if (W.sp + n > S.cap) {
             uint32_t *g = S.spill + (size_t)W.spill * (64 * kSpillBlock);
             uint32_t e[kSpillBlock];
@@ -725,9 +729,10 @@ __device__ __forceinline__ void sah_stack_reserve(const SahStack &S, SahWalk &W,
     }
 }
 // The lane's LDS part is empty: fetch its latest block back, if there is one.  Returns false when the whole stack is empty.
+template <int kSpill>
 __device__ __forceinline__ bool sah_stack_refill(const SahStack &S, SahWalk &W)
 {
-    if (W.spill == 0) return false;
+    if (kSpill == 0 || W.spill == 0) return false;
     W.spill--;
     const uint32_t *g = S.spill + (size_t)W.spill * (64 * kSpillBlock);
     const uint4 a = reinterpret_cast<const uint4 *>(g)[0], b = reinterpret_cast<const uint4 *>(g)[1];
@@ -794,7 +799,7 @@ __device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W,
 {
     uint32_t *const stack = S.lds;
     const int stride = S.stride;
-    sah_stack_reserve(S, W, 1);
+    sah_stack_reserve<2>(S, W, 1);
     const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
     const float4 a = np[0], b = np[1], c = np[2], lf = np[3];
     const uint32_t llink = __float_as_uint(lf.x), lcnt = __float_as_uint(lf.y);
@@ -843,7 +848,7 @@ __device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W,
         W.pair = left_first ? llink : rlink;
     } else if (gl || gr) {
         W.pair = gl ? llink : rlink;
-    } else if (W.sp == 0 && !sah_stack_refill(S, W)) {
+    } else if (W.sp == 0 && !sah_stack_refill<2>(S, W)) {
         W.pair = kNoPair;
     } else {
         W.sp--;
@@ -863,19 +868,21 @@ __device__ __forceinline__ void sahw_take(SahWalk &W, uint32_t x)
     if (x & 15u) { W.k0 = x & ~15u; W.n0 = x & 15u; }
     else W.pair = x;
 }
+template <int kSpill>
 __device__ __forceinline__ void sahw_pop(SahWalk &W, const SahStack &S)
 {
-    if (W.sp > 0 || sah_stack_refill(S, W)) {
+    if (W.sp > 0 || sah_stack_refill<kSpill>(S, W)) {
         W.sp--;
         sahw_take(W, S.lds[W.sp * S.stride]);
     }
 }
 
+template <int kSpill>
 __device__ __forceinline__ bool sahw_tri_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin, const SahStack &S,
                                               uint32_t &n_tri)
 {
     (void)sah_tri_step(P, W, o, d, tmin, n_tri);          // (k1 / n1 are never set in this form: the range just ends)
-    if ((W.n0 == 0) & (W.pair == kNoPair)) sahw_pop(W, S);
+    if ((W.n0 == 0) & (W.pair == kNoPair)) sahw_pop<kSpill>(W, S);
     return sah_walking(W);
 }
 
@@ -896,13 +903,15 @@ __device__ __forceinline__ void sahw_order(float &ka, uint32_t &la, float &kb, u
     const uint32_t l = swap ? lb : la; lb = swap ? la : lb; la = l;
 }
 
+// kTop: 0 = every record from memory, 1 = the tree's top levels from the workgroup's LDS copy, 2 = decided per launch
+template <int kTop, int kSpill>
 __device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, const SahStack &S, uint32_t &n_box)
 {
     uint32_t *const stack = S.lds;
     const int stride = S.stride;
-    sah_stack_reserve(S, W, 3);
+    sah_stack_reserve<kSpill>(S, W, 3);
     float4 q0, q1, q2, lk, q4, q5, q6;
-    if (S.top_bytes == 0u) {
+    if (kTop == 0 || (kTop == 2 && S.top_bytes == 0u)) {
         const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
         q0 = np[0]; q1 = np[1]; q2 = np[2]; lk = np[3]; q4 = np[4]; q5 = np[5]; q6 = np[6];
     } else {
@@ -928,7 +937,7 @@ __device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W
     if (k2 < inf) { stack[W.sp * stride] = l2; W.sp++; }
     if (k1 < inf) { stack[W.sp * stride] = l1; W.sp++; }
     if (k0 < inf) sahw_take(W, l0);
-    else sahw_pop(W, S);
+    else sahw_pop<kSpill>(W, S);
     return sah_walking(W);
 }
 
@@ -948,13 +957,14 @@ __device__ __forceinline__ void sahq_slab(uint32_t lo, uint32_t hi, float ox, fl
     key = present ? k : __builtin_inff();
 }
 
+template <int kTop, int kSpill>
 __device__ __forceinline__ bool sahq_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, const SahStack &S, uint32_t &n_box)
 {
     uint32_t *const stack = S.lds;
     const int stride = S.stride;
-    sah_stack_reserve(S, W, 3);
+    sah_stack_reserve<kSpill>(S, W, 3);
     float4 q0, q1, q2, lk;
-    if (S.top_bytes == 0u) {
+    if (kTop == 0 || (kTop == 2 && S.top_bytes == 0u)) {
         const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
         q0 = np[0]; q1 = np[1]; q2 = np[2]; lk = np[3];
     } else {
@@ -978,7 +988,7 @@ __device__ __forceinline__ bool sahq_node_step(const RenderParams &P, SahWalk &W
     if (k2 < inf) { stack[W.sp * stride] = l2; W.sp++; }
     if (k1 < inf) { stack[W.sp * stride] = l1; W.sp++; }
     if (k0 < inf) sahw_take(W, l0);
-    else sahw_pop(W, S);
+    else sahw_pop<kSpill>(W, S);
     return sah_walking(W);
 }
 
@@ -1014,9 +1024,9 @@ __device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, f
     sah_begin(W, d, tmax0);
     const SahStack S = {stack, stride, P.stack_cap, nullptr, nullptr, nullptr, 0u};      // the whole stack in LDS: stack_cap is out of reach
     if (P.sah == 3) {
-        while (W.n0 != 0 ? sahw_tri_step(P, W, o, d, tmin, S, n_tri) : sahq_node_step(P, W, o, d, S, n_box)) {}
+        while (W.n0 != 0 ? sahw_tri_step<0>(P, W, o, d, tmin, S, n_tri) : sahq_node_step<0, 0>(P, W, o, d, S, n_box)) {}
     } else if (P.sah == 2) {
-        while (W.n0 != 0 ? sahw_tri_step(P, W, o, d, tmin, S, n_tri) : sahw_node_step(P, W, o, d, S, n_box)) {}
+        while (W.n0 != 0 ? sahw_tri_step<0>(P, W, o, d, tmin, S, n_tri) : sahw_node_step<0, 0>(P, W, o, d, S, n_box)) {}
     } else {
         while (sah_step(P, W, o, d, tmin, S, n_box, n_tri)) {}
     }
