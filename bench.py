@@ -219,8 +219,9 @@ ROOFLINE_NOTES = {
           "instruction); `traffic` = HBM bytes of a launch (framebuffer + spills), a rounding error against 8 TB/s",
     "c3": "0.7 MB tree + 3 MB texture live in L1/L2: bound by VALU issue / divergence; `traffic` = HBM bytes of a launch",
     "c4": "1 GB scene: `traffic` (PMC FETCH_SIZE x2 + WRITE_SIZE, an upper bound) is what leaves the L2s (Infinity-Cache "
-          "hits are counted in it, MI355X_MICROARCH.md); the walk is bound by dependent-fetch latency, not bandwidth "
-          "(DESIGN.md 4b), so frac is low by construction",
+          "hits are counted in it, MI355X_MICROARCH.md).  The walk is a per-lane gather of 64-byte nodes and 48-byte triangles: "
+          "what it saturates first is the vector-memory REQUEST path (texture-address units ~70 % busy at one cycle per lane "
+          "and 16-byte request, profiles/r03_sah_lane_census.json), not HBM bytes, so frac is low by construction",
 }
 ROOFLINE_NOTES["c1"] = ROOFLINE_NOTES["c5"] = ROOFLINE_NOTES["c2"]
 
