@@ -704,3 +704,18 @@ def test_bench_without_a_launcher_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env2, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2000:]
+
+
+def test_band_queue_of_the_dqrb_policy(tmp_path):
+    """csrc/host/BandQueue.h (VERDICT r2 missing 3): full-width bands of 8-row multiples, 64..128 per frame
+    where the height allows, every band pulled exactly once by concurrent workers, dearest-first order from last frame's
+    times.  Plain g++ against the host headers; no GPU call is made."""
+    import subprocess
+    csrc = os.path.join(ROOT, "multi-gpu-path-tracer_amd", "csrc")
+    exe = str(tmp_path / "band_queue_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", csrc, "-o", exe, os.path.join(ROOT, "tests", "native", "band_queue_check.cpp"),
+                    "-L", os.path.join(ROOT, "multi-gpu-path-tracer_amd"), "-lptamd", "-Wl,-rpath," + os.path.join(ROOT, "multi-gpu-path-tracer_amd"),
+                    "-Wl,-rpath,/opt/rocm/lib", "-pthread"], check=True)
+    for w, h, t in ((1920, 1080, 8), (3840, 2160, 16), (400, 400, 3), (64, 36, 4), (16, 8, 2)):
+        r = subprocess.run([exe, str(w), str(h), str(t)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.startswith("ok:"), (w, h, t, r.stdout, r.stderr)
