@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Full-size oracle fixtures: the frames BASELINE.json's configs are quoted on, rendered ONCE by the CPU oracle
 (oracle/pt_oracle.c) and kept as sha256(RGB || YUV) + the exact work counters + one sha256 per band of 8 framebuffer
-rows (so that a mismatch on the GPU box names the rows).  ~3 min (box) and ~8 min (duck) on 8 threads; the GPU suite
+rows (so that a mismatch on the GPU box names the rows).  ~3 min (C2 box), ~8 min (duck) and ~40 min (C5 box) on 8 threads; the GPU suite
 compares the HIP path's frame with these at the size bench.py runs (tests/test_gpu_pipeline.py).
 
   python tests/golden/make_fullsize.py [case ...]
@@ -27,6 +27,10 @@ CASES = {
     # configs[2]'s scene and frame size at the sample count the oracle finishes in minutes (reference tree: 2 120
     # triangle tests per segment)
     "duck_1920x1080_16spp_8b": ("duck", DUCK_CAMERA, 1920, 1080, 16, 8),
+    # configs[2] (C3) at its full sample count: 1.33e9 segments x 2 120 triangle tests, ~2 h on 8 threads
+    "duck_1920x1080_256spp_8b": ("duck", DUCK_CAMERA, 1920, 1080, 256, 8),
+    # BASELINE.json configs[4] (C5) at its full size: 2.1e10 segments, ~40 min on 8 threads
+    "box_3840x2160_1024spp_16b": ("box", BOX_CAMERA, 3840, 2160, 1024, 16),
 }
 KEYS = ("paths", "segments", "box_tests", "tri_tests", "light_tests")
 
