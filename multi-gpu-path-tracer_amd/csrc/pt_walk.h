@@ -882,6 +882,10 @@ __device__ __forceinline__ bool sahw_tri_step(const RenderParams &P, SahWalk &W,
                                               uint32_t &n_tri)
 {
     (void)sah_tri_step(P, W, o, d, tmin, n_tri);          // (k1 / n1 are never set in this form: the range just ends)
+    // A triangle trip finishes its leaf (<= 4 triangles) instead of leaving the second pair to another vote: the same tests
+    // in the same order for the lane, one trip of the wave less (C3 110.3 -> 106.9 ms, C4 52.8 -> 51.5 ms).  Going on with a
+    // leaf that comes off the stack right after it loses: C3 129 ms, C4 60 ms.
+    if (pt_ballot(W.n0 != 0) != 0ull) { if (W.n0 != 0) (void)sah_tri_step(P, W, o, d, tmin, n_tri); }
     if ((W.n0 == 0) & (W.pair == kNoPair)) sahw_pop<kSpill>(W, S);
     return sah_walking(W);
 }
