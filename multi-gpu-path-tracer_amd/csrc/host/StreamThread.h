@@ -69,7 +69,9 @@ public:
                 if (gatherOnWorker_) devicePathTracer->gatherTask(task, stream);
             }
             barrier_.wait();                       // frame end
-            if (shouldTerminate) return;
+            // (No termination check here: RenderManager::reset() raises the flag and then joins the frame-START barrier with
+            // every worker.  A worker that left after the frame-end barrier -- the flag can already be up when it wakes, if
+            // the frame was short -- would never arrive there, and the ones that did would wait for it forever.)
         }
     }
 
