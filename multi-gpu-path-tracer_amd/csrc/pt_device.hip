@@ -241,7 +241,7 @@ struct MaskDealtWalk {
 };
 
 template <bool kInPlace>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_WAVES, PT_DEAL_WAVES))) void render_kernel_dealt(RenderParams P)
+__device__ __forceinline__ void render_kernel_dealt_impl(const RenderParams &P)
 {
     extern __shared__ float4 lds_raw[];
     const int tid = threadIdx.x;
@@ -251,6 +251,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
     Wk.V = stage_shade_lds(P, LL.tail, tid, kBlock);      // the host picks this kernel only when the tables fit
     Wk.D = deal_carve(P, Wk.V.end, tid, kBlock);
     render_dealt_body(P, Wk, lane);
+}
+template <bool kInPlace>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_WAVES, PT_DEAL_WAVES))) void render_kernel_dealt(RenderParams P)
+{
+    render_kernel_dealt_impl<kInPlace>(P);
+}
+// The same kernel built for eight waves per SIMD (64 VGPRs, 21 of the 7-wave build's registers spilled): for launches that
+// fill the device more than twice over the eighth wave buys more than the spills cost (C2 59.7 -> 58.9 ms, C5 878 -> 874 ms);
+// a rank's share, whose time is one wave's chain, loses to them (an eighth of C2 14.6 -> 15.5 ms) and keeps the build above.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void render_kernel_dealt8(RenderParams P)
+{
+    render_kernel_dealt_impl<true>(P);
 }
 
 // kWalk 5: the stack walk with dealt sparse leaves (traverse_uniform_stack_dealt) for trees of up to 4 096 inner nodes (the
@@ -860,6 +872,7 @@ struct pt_device {
     int split_pct = 0;           // ... when the dearest costs at least this % of an evenly spread launch's share per slot (0: 110 dealt, 90 SAH; PTAMD_SPLIT_PCT)
     int deal_split = 4;           // dealt kernel: likewise (PTAMD_DEAL_SPLIT: 0 off, 2, 4, 8)
     int sah_split = 16;           // SAH kernel: waves a critically dear tile is handed to (PTAMD_SAH_SPLIT: 0 off, 16, 32, 64)
+    bool deal_dense = true;       // dealt mask walk: the 8-wave build for launches of more than 2 x the device's wave slots (PTAMD_DEAL_DENSE=0: never)
     int resident_cap = 0;         // persistent kernels: at most this many workgroups per CU (PTAMD_RESIDENT; 0 = what fits)
     int sah_stack_lds = 16;       // persistent SAH kernel: stack entries per lane kept in LDS, deeper ones spill to device memory (PTAMD_SAH_STACK: 0 = all in LDS, else 11..64)
     struct Resident { const void *kern; size_t lds; int blocks; };
@@ -978,6 +991,7 @@ try {
     if (const char *e = getenv("PTAMD_DEAL_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 2 || v == 4 || v == 8) d->deal_split = v; }
     if (const char *e = getenv("PTAMD_SAH_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) d->sah_split = v; }
     if (const char *e = getenv("PTAMD_SAH_STACK")) { const int v = atoi(e); if (v == 0 || (v >= 11 && v <= 64)) { d->sah_stack_lds = v; d->sah_by_hand = true; } }
+    if (const char *e = getenv("PTAMD_DEAL_DENSE")) d->deal_dense = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_RESIDENT")) { const int v = atoi(e); if (v >= 1 && v <= 16) d->resident_cap = v; }
     if (const char *e = getenv("PTAMD_FOLD_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 31) d->fold_bits = v; }
     if (const char *e = getenv("PTAMD_COOP")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->coop_mode = v; }
@@ -1511,9 +1525,10 @@ static TileSchedule *schedule_for(pt_device *dev, const RenderParams &P, unsigne
 typedef void (*RenderKernel)(RenderParams);
 struct KernelChoice { RenderKernel fn; const char *name; };
 #define PT_KERNEL(...) KernelChoice{__VA_ARGS__, "pt::" #__VA_ARGS__}
-static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool stage, bool packed, bool lean = false)
+static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool stage, bool packed, bool lean = false, bool dense = false)
 {
     if (lean) return PT_KERNEL(dev::render_kernel_sahw_lean);
+    if (dense && walk == 4 && dev->deal_min <= 64) return PT_KERNEL(dev::render_kernel_dealt8);
     if (walk == 3 && dev->sah_persistent) {
         const size_t scene_bytes = dev->n_pairs * sizeof(NodePair) + dev->n_tris * sizeof(TriIsect);
         (void)scene_bytes;      // round 1 picked the 6-wave build for cache-resident scenes; after round 2's diet the natural
@@ -1611,7 +1626,9 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         P.top_record_bytes = dev->sah_quant_on ? 64 : 128;
     }
     const size_t lds = lds_bytes(P, dev::kBlock, stage);
-    const KernelChoice choice = pick_kernel(dev, walk, coop, stage, packed, lean);
+    // dealt mask walk: launches with more than twice as many tiles as the device has wave slots take the 8-wave build
+    const bool dense = walk == 4 && dev->deal_dense && tiles >= 2ll * dev->max_waves;
+    const KernelChoice choice = pick_kernel(dev, walk, coop, stage, packed, lean, dense);
     const RenderKernel kern = choice.fn;
     {
         const pt_status st = ensure_lds(dev, (const void *)kern, lds);
