@@ -549,9 +549,11 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 // to the spills (C4 84 -> 88 ms), so it keeps the natural allocation.
 __global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P) { render_sah_body<0>(P); }
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_sah6(RenderParams P) { render_sah_body<0>(P); }
-// the 4-wide form of the tree (RenderParams::sah == 2), cache-resident trees: top levels in LDS, short stack (together they
-// leave room for five workgroups per CU: whole stacks + the top levels are 35 KB per workgroup on the duck, four per CU)
-__global__ __launch_bounds__(kBlock) void render_kernel_sahw(RenderParams P) { render_sah_body<1, 1, 1>(P); }
+// the 4-wide form of the tree (RenderParams::sah == 2), cache-resident trees: top levels in LDS, short stack (24 KB per
+// workgroup on the duck; whole stacks + the top levels would be 35 KB, four workgroups per CU), built for SIX waves per SIMD
+// (80 VGPRs, 28 B of scratch per lane): such trees are bound by instruction issue, and with the LDS out of the way the sixth
+// wave pays for its spills (C3 107.3 -> 102.5 ms; the 64-byte-node kernel, bound by the request path, gains nothing)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_sahw(RenderParams P) { render_sah_body<1, 1, 1>(P); }
 // ... for launches with fewer tiles than the device has wave slots (a rank's share of a multi-GPU frame): nothing but the walk
 __global__ __launch_bounds__(kBlock) void render_kernel_sahw_lean(RenderParams P) { render_sah_body<1, 0, 0>(P); }
 // the 4-wide form in 64-byte records (RenderParams::sah == 3), trees beyond the caches: short LDS stack + overflow area
