@@ -553,7 +553,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 // workgroup on the duck; whole stacks + the top levels would be 35 KB, four workgroups per CU), built for SIX waves per SIMD
 // (80 VGPRs, 28 B of scratch per lane): such trees are bound by instruction issue, and with the LDS out of the way the sixth
 // wave pays for its spills (C3 107.3 -> 102.5 ms; the 64-byte-node kernel, bound by the request path, gains nothing)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_sahw(RenderParams P) { render_sah_body<1, 1, 1>(P); }
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_sahw6(RenderParams P) { render_sah_body<1, 1, 1>(P); }
+// ... and at its natural allocation (five waves, no spills) for launches of less than twice the device's wave slots, whose
+// chains the spills lengthen (a quarter of the duck's frame: 49.0 ms against 52.1 ms with the six-wave build)
+__global__ __launch_bounds__(kBlock) void render_kernel_sahw(RenderParams P) { render_sah_body<1, 1, 1>(P); }
 // ... for launches with fewer tiles than the device has wave slots (a rank's share of a multi-GPU frame): nothing but the walk
 __global__ __launch_bounds__(kBlock) void render_kernel_sahw_lean(RenderParams P) { render_sah_body<1, 0, 0>(P); }
 // the 4-wide form in 64-byte records (RenderParams::sah == 3), trees beyond the caches: short LDS stack + overflow area
@@ -874,6 +877,7 @@ struct pt_device {
     int split_pct = 0;           // ... when the dearest costs at least this % of an evenly spread launch's share per slot (0: 110 dealt, 90 SAH; PTAMD_SPLIT_PCT)
     int deal_split = 4;           // dealt kernel: likewise (PTAMD_DEAL_SPLIT: 0 off, 2, 4, 8)
     int sah_split = 16;           // SAH kernel: waves a critically dear tile is handed to (PTAMD_SAH_SPLIT: 0 off, 16, 32, 64)
+    int lean_pct = 100;           // SAH tree, cache-resident: launches of up to this % of the device's wave slots take the lean kernel (PTAMD_LEAN_PCT)
     bool deal_dense = true;       // dealt mask walk: the 8-wave build for launches of more than 2 x the device's wave slots (PTAMD_DEAL_DENSE=0: never)
     int resident_cap = 0;         // persistent kernels: at most this many workgroups per CU (PTAMD_RESIDENT; 0 = what fits)
     int sah_stack_lds = 16;       // persistent SAH kernel: stack entries per lane kept in LDS, deeper ones spill to device memory (PTAMD_SAH_STACK: 0 = all in LDS, else 11..64)
@@ -993,6 +997,7 @@ try {
     if (const char *e = getenv("PTAMD_DEAL_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 2 || v == 4 || v == 8) d->deal_split = v; }
     if (const char *e = getenv("PTAMD_SAH_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) d->sah_split = v; }
     if (const char *e = getenv("PTAMD_SAH_STACK")) { const int v = atoi(e); if (v == 0 || (v >= 11 && v <= 64)) { d->sah_stack_lds = v; d->sah_by_hand = true; } }
+    if (const char *e = getenv("PTAMD_LEAN_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 1000) d->lean_pct = v; }
     if (const char *e = getenv("PTAMD_DEAL_DENSE")) d->deal_dense = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_RESIDENT")) { const int v = atoi(e); if (v >= 1 && v <= 16) d->resident_cap = v; }
     if (const char *e = getenv("PTAMD_FOLD_BITS")) { const int v = atoi(e); if (v >= 8 && v <= 31) d->fold_bits = v; }
@@ -1537,7 +1542,7 @@ static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool 
                                 // (5-wave, spill-free) build is as fast there (C3 132.9 vs 133.8 ms) and faster on C4
         const bool six = dev->sah_waves == 6;
         if (dev->sah_quant_on) return dev->sah_by_hand ? PT_KERNEL(dev::render_kernel_sahq_any) : PT_KERNEL(dev::render_kernel_sahq);
-        if (dev->sah_wide_on) return dev->sah_by_hand ? PT_KERNEL(dev::render_kernel_sahw_any) : PT_KERNEL(dev::render_kernel_sahw);
+        if (dev->sah_wide_on) return dev->sah_by_hand ? PT_KERNEL(dev::render_kernel_sahw_any) : dense ? PT_KERNEL(dev::render_kernel_sahw6) : PT_KERNEL(dev::render_kernel_sahw);
         return six ? PT_KERNEL(dev::render_kernel_sah6) : PT_KERNEL(dev::render_kernel_sah);
     }
     if (walk == 3) return PT_KERNEL(dev::render_kernel<false, true, 3>);
@@ -1609,7 +1614,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     if (walk == 3 && dev->sah_persistent && dev->sah_wide_on && !dev->sah_quant_on && !dev->sah_by_hand) {
         const size_t lds_lean = lds_bytes(P, dev::kBlock, stage);            // P still has whole stacks and no top levels here
         const long long slots = (long long)dev->cu_count * resident_per_cu(dev, (const void *)dev::render_kernel_sahw_lean, lds_lean) * dev::kWavesPerBlock;
-        lean = tiles <= slots;
+        lean = tiles * 100ll <= slots * (long long)dev->lean_pct;
     }
     const bool short_stack = !lean;
     const bool top_levels = !lean && (dev->sah_by_hand || !dev->sah_quant_on);
@@ -1629,7 +1634,9 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     }
     const size_t lds = lds_bytes(P, dev::kBlock, stage);
     // dealt mask walk: launches with more than twice as many tiles as the device has wave slots take the 8-wave build
-    const bool dense = walk == 4 && dev->deal_dense && tiles >= 2ll * dev->max_waves;
+    // (likewise the SAH kernel of cache-resident trees: its six-wave build)
+    const bool dense = (walk == 4 || (walk == 3 && dev->sah_persistent && dev->sah_wide_on && !dev->sah_quant_on)) && dev->deal_dense &&
+                       tiles >= (walk == 4 ? 2ll * dev->max_waves : 2ll * dev->cu_count * 6 * dev::kWavesPerBlock);
     const KernelChoice choice = pick_kernel(dev, walk, coop, stage, packed, lean, dense);
     const RenderKernel kern = choice.fn;
     {
