@@ -145,10 +145,13 @@ class OracleScene:
             yuv = np.zeros(total + 2 * (total // 4), np.uint8)
         tw, th, ox, oy = task if task is not None else (width, height, 0, 0)
         threads = max(1, min(threads, th))
+        # eight strips per thread, handed out as the threads come free: rows differ many-fold in cost (the duck's rows
+        # against the background's), and one strip per thread left most threads idle for most of a full-size frame
+        n_strips = threads if threads == 1 else min(th, threads * 8)
         strips = []
-        for i in range(threads):
-            y0 = oy + (th * i) // threads
-            y1 = oy + (th * (i + 1)) // threads
+        for i in range(n_strips):
+            y0 = oy + (th * i) // n_strips
+            y1 = oy + (th * (i + 1)) // n_strips
             if y1 > y0:
                 strips.append(_Task(tw, y1 - y0, ox, y0))
         counters = [_Counters() for _ in strips]
@@ -160,7 +163,7 @@ class OracleScene:
         if len(strips) == 1:
             rcs = [run(0)]
         else:
-            with ThreadPoolExecutor(max_workers=len(strips)) as ex:
+            with ThreadPoolExecutor(max_workers=threads) as ex:
                 rcs = list(ex.map(run, range(len(strips))))
         if any(rcs):
             raise RuntimeError("ptor_render failed: %s" % rcs)
