@@ -1435,7 +1435,7 @@ static size_t lds_bytes(const RenderParams &P, int block, bool stage)
         f4 += (size_t)P.n_tris * 3 /* onb table, stage_shade_lds */ + (size_t)P.n_tris * 3 +
               (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 2 + 15) / 16);
     if (P.deal_cap > 0 && P.stack_entries != 0)       // dev::deal_carve32 (kWalk 5: stack walk, 32-bit items, no triangle table)
-        f4 += (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 4 + 15) / 16);
+        f4 += (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 4 + 15) / 16 + 3 * (size_t)dev::kStageTris);
     return f4 * 16;
 }
 

@@ -217,12 +217,14 @@ __device__ __forceinline__ DealView32 deal_carve32(const RenderParams &P, float4
 {
     DealView32 D;
     const int wave = tid / kWave;
-    const size_t per_wave_f4 = (size_t)kWave + kWave / 2 + kWave / 2 + ((size_t)P.deal_cap * 4 + 15) / 16;
+    const size_t items_f4 = ((size_t)P.deal_cap * 4 + 15) / 16;
+    const size_t per_wave_f4 = (size_t)kWave + kWave / 2 + kWave / 2 + items_f4 + 3 * (size_t)kStageTris;
     float4 *w = lds + (size_t)wave * per_wave_f4;
     D.ray_a = w;
     D.keys = reinterpret_cast<unsigned long long *>(w + kWave);
     D.ray_b = reinterpret_cast<float2 *>(w + kWave + kWave / 2);
     D.items = reinterpret_cast<uint32_t *>(w + kWave + kWave);
+    D.stage = w + kWave + kWave + items_f4;
     D.cap = P.deal_cap;
     D.deal_min = P.deal_min;
     return D;
