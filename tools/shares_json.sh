@@ -19,3 +19,4 @@ run() {   # <label> <bench args...>
 run c2 --config c2
 run c3_sah --config c3 --bvh sah
 run c5 --config c5
+run c3_ref --config c3
