@@ -282,7 +282,7 @@ struct StackDealtWalk {
     __device__ __forceinline__ void shade_hit(PathState &L, const RenderParams &P, const Hit &h) const { shade<false, ShadeView>(L, P, V, h); }
 };
 
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_STACK_WAVES, PT_DEAL_STACK_WAVES))) void render_kernel_dealt_stack(RenderParams P)
+__device__ __forceinline__ void render_kernel_dealt_stack_impl(const RenderParams &P)
 {
     extern __shared__ float4 lds_raw[];
     const int tid = threadIdx.x;
@@ -293,6 +293,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
     Wk.D = deal_carve32(P, Wk.V.end, tid);
     Wk.stack = LL.stack + tid;
     render_dealt_body(P, Wk, lane);
+}
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_STACK_WAVES, PT_DEAL_STACK_WAVES))) void render_kernel_dealt_stack(RenderParams P)
+{
+    render_kernel_dealt_stack_impl(P);
+}
+// Built for six waves per SIMD (80 VGPRs, 76 B of scratch per lane), run with a 384-entry item list so that six workgroups fit a
+// CU's LDS: for launches of more than twice the device's wave slots (C3 with the reference's tree 3 862 -> 3 716 ms; the five-
+// wave build with the same list: 3 916 ms).  Round 2 found no gain in a sixth wave: then the waves of a SIMD still stalled
+// together on the dense leaf's scalar-cache misses.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_dealt_stack6(RenderParams P)
+{
+    render_kernel_dealt_stack_impl(P);
 }
 
 // Cooperative kernel for reference trees with big leaves (cornell_duck: one leaf of 1603 triangles, 2 120
@@ -834,6 +846,7 @@ struct pt_device {
     bool sah_quant_on = false;    // ... and the uploaded scene has it
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
     int spec_pct = -1;            // ... and leaves the walk loop when <= this % of the walkers remain; -1 = by scene size (fill_params)
+    bool deal_cap_by_hand = false; // PTAMD_DEAL_CAP given
     int deal_cap = 768, deal_min = 48;   // dealt walk (kWalk 4): item list capacity per wave; in-place threshold (lanes)
     int sah_waves = 0;            // SAH kernel build: 0 = by scene size, 5 / 6 = force (PTAMD_SAH_WAVES, A/B runs)
     int lrpt = 1;                 // dealt kernel: issue priority by remaining samples (PTAMD_LRPT=0: off)
@@ -990,7 +1003,7 @@ try {
     if (const char *e = getenv("PTAMD_LRPT")) d->lrpt = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_SAH_WAVES")) { const int v = atoi(e); if (v == 5 || v == 6) d->sah_waves = v; }
     if (const char *e = getenv("PTAMD_DEAL_MIN")) { const int v = atoi(e); if (v >= 0 && v <= 65) d->deal_min = v; }
-    if (const char *e = getenv("PTAMD_DEAL_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 8192) d->deal_cap = v & ~7; }
+    if (const char *e = getenv("PTAMD_DEAL_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 8192) { d->deal_cap = v & ~7; d->deal_cap_by_hand = true; } }
     if (const char *e = getenv("PTAMD_SCHED_MIN_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 1 << 20) d->sched_min_blocks = v; }
     if (const char *e = getenv("PTAMD_SPLIT_RATIO")) { const int v = atoi(e); if (v >= 1 && v <= 100) d->split_ratio = v; }
     if (const char *e = getenv("PTAMD_SPLIT_PCT")) { const int v = atoi(e); if (v >= 10 && v <= 1000) d->split_pct = v; }
@@ -1536,6 +1549,7 @@ static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool 
 {
     if (lean) return PT_KERNEL(dev::render_kernel_sahw_lean);
     if (dense && walk == 4 && dev->deal_min <= 64) return PT_KERNEL(dev::render_kernel_dealt8);
+    if (dense && walk == 5 && !coop) return PT_KERNEL(dev::render_kernel_dealt_stack6);
     if (walk == 3 && dev->sah_persistent) {
         const size_t scene_bytes = dev->n_pairs * sizeof(NodePair) + dev->n_tris * sizeof(TriIsect);
         (void)scene_bytes;      // round 1 picked the 6-wave build for cache-resident scenes; after round 2's diet the natural
@@ -1594,6 +1608,12 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     if (walk != 0) P.queue_entries = 0;
     if (walk == 1 || walk == 4) P.stack_entries = 0;
     P.deal_cap = (walk == 4 || walk == 5) ? dev->deal_cap : 0;
+    // Launches with more than twice as many tiles as the device has wave slots are bound by throughput and take the builds
+    // with one more wave per SIMD (dealt mask walk: eight; dealt stack walk and the SAH kernel of cache-resident trees: six);
+    // smaller ones, whose time is some wave's chain, keep the spill-free builds.
+    const bool dense = (walk == 4 || walk == 5 || (walk == 3 && dev->sah_persistent && dev->sah_wide_on && !dev->sah_quant_on)) && dev->deal_dense &&
+                       tiles >= (walk == 4 ? 2ll * dev->max_waves : 2ll * dev->cu_count * 6 * dev::kWavesPerBlock);
+    if (dense && walk == 5 && !dev->deal_cap_by_hand) P.deal_cap = 384;      // six workgroups' item lists and stacks in a CU's LDS
     // big leaves + stack walk: four waves per tile, each testing a quarter of every leaf (render_kernel_coop)
     // It pays when the launch is small for the machine (a rank's share of a multi-GPU frame): measured on
     // the duck, 1/6 of a 1080p frame and less gains (1/8: 1.85 -> 1.09 s), 1/4 and more loses (whole frame
@@ -1633,10 +1653,6 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         P.top_record_bytes = dev->sah_quant_on ? 64 : 128;
     }
     const size_t lds = lds_bytes(P, dev::kBlock, stage);
-    // dealt mask walk: launches with more than twice as many tiles as the device has wave slots take the 8-wave build
-    // (likewise the SAH kernel of cache-resident trees: its six-wave build)
-    const bool dense = (walk == 4 || (walk == 3 && dev->sah_persistent && dev->sah_wide_on && !dev->sah_quant_on)) && dev->deal_dense &&
-                       tiles >= (walk == 4 ? 2ll * dev->max_waves : 2ll * dev->cu_count * 6 * dev::kWavesPerBlock);
     const KernelChoice choice = pick_kernel(dev, walk, coop, stage, packed, lean, dense);
     const RenderKernel kern = choice.fn;
     {
