@@ -153,6 +153,8 @@ __device__ __forceinline__ void render_dealt_body(const RenderParams &P, const W
 #endif
         const SlotWork sw = slot_work(K, slot, n_split, parts, lane);
         const int tile = sw.tile;
+        // a part's rays sit in its first 64 / parts lanes; walks that can (MaskDealtWalk with the boxes staged) spread them
+        const int part_lanes = sw.is_part ? (int)(64u / parts) : 0;
         int x, y, pixel_index;
         const bool in_frame = tile_pixel(K, tile, sw.tile_lane, x, y, pixel_index) && sw.lane_on;
         PathState L;
@@ -195,7 +197,7 @@ __device__ __forceinline__ void render_dealt_body(const RenderParams &P, const W
                 wave_seg += (uint32_t)__popcll(trace_mask);
                 trips++;
             }
-            const Hit h = Wk.hit(P, lane, trace, L.ro, L.rd, wave_box, wave_tri);
+            const Hit h = Wk.hit(P, lane, trace, L.ro, L.rd, wave_box, wave_tri, part_lanes);
 #ifdef PT_STAMPS
             const unsigned long long st2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -228,26 +230,27 @@ __device__ __forceinline__ void render_dealt_body(const RenderParams &P, const W
 }
 
 // kWalk 4: the mask walk with dealt sparse leaves (traverse_uniform_dealt), shading tables, triangle and onb tables in LDS.
-template <bool kInPlace>
+template <bool kInPlace, bool kParts = true>
 struct MaskDealtWalk {
     ShadeViewLds V;
     DealView D;
     __device__ __forceinline__ Hit hit(const RenderParams &P, int lane, bool trace, const v3 &ro, const v3 &rd,
-                                       unsigned long long &wave_box, unsigned long long &wave_tri) const
+                                       unsigned long long &wave_box, unsigned long long &wave_tri, int part_lanes) const
     {
-        return traverse_uniform_dealt<kInPlace>(P, D, lane, trace, ro, rd, 0.001f, 3.402823466e+38f, wave_box, wave_tri);
+        return traverse_uniform_dealt<kInPlace>(P, D, lane, trace, ro, rd, 0.001f, 3.402823466e+38f, wave_box, wave_tri,
+                                                kParts && D.boxes ? part_lanes : 0);
     }
     __device__ __forceinline__ void shade_hit(PathState &L, const RenderParams &P, const Hit &h) const { shade<false, ShadeViewLds>(L, P, V, h); }
 };
 
-template <bool kInPlace>
+template <bool kInPlace, bool kParts = true>
 __device__ __forceinline__ void render_kernel_dealt_impl(const RenderParams &P)
 {
     extern __shared__ float4 lds_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const LdsLayout LL = lds_carve<false>(P, lds_raw, kBlock);
-    MaskDealtWalk<kInPlace> Wk;
+    MaskDealtWalk<kInPlace, kParts> Wk;
     Wk.V = stage_shade_lds(P, LL.tail, tid, kBlock);      // the host picks this kernel only when the tables fit
     Wk.D = deal_carve(P, Wk.V.end, tid, kBlock);
     render_dealt_body(P, Wk, lane);
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_DEAL_
 // a rank's share, whose time is one wave's chain, loses to them (an eighth of C2 14.6 -> 15.5 ms) and keeps the build above.
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void render_kernel_dealt8(RenderParams P)
 {
-    render_kernel_dealt_impl<true>(P);
+    render_kernel_dealt_impl<true, false>(P);       // (dense launches never split: no part code in this build)
 }
 
 // kWalk 5: the stack walk with dealt sparse leaves (traverse_uniform_stack_dealt) for trees of up to 4 096 inner nodes (the
@@ -275,7 +278,7 @@ struct StackDealtWalk {
     DealView32 D;
     uint32_t *stack;
     __device__ __forceinline__ Hit hit(const RenderParams &P, int lane, bool trace, const v3 &ro, const v3 &rd,
-                                       unsigned long long &wave_box, unsigned long long &wave_tri) const
+                                       unsigned long long &wave_box, unsigned long long &wave_tri, int /*part_lanes: parts walk like whole tiles here*/) const
     {
         return traverse_uniform_stack_dealt(P, D, lane, trace, ro, rd, 0.001f, 3.402823466e+38f, stack, kBlock, wave_box, wave_tri);
     }
@@ -889,6 +892,7 @@ struct pt_device {
     int split_ratio = 0;          // ... and every tile dearer than this share of the dearest (0: 65 % dealt, 80 % SAH; PTAMD_SPLIT_RATIO)
     int split_pct = 0;           // ... when the dearest costs at least this % of an evenly spread launch's share per slot (0: 110 dealt, 90 SAH; PTAMD_SPLIT_PCT)
     int deal_split = 4;           // dealt kernel: likewise (PTAMD_DEAL_SPLIT: 0 off, 2, 4, 8)
+    bool part_lanes = true;       // dealt mask walk: parts of split tiles test all child boxes at once, lanes = (ray, box) (PTAMD_PART_LANES)
     int sah_split = 16;           // SAH kernel: waves a critically dear tile is handed to (PTAMD_SAH_SPLIT: 0 off, 16, 32, 64)
     int lean_pct = 100;           // SAH tree, cache-resident: launches of up to this % of the device's wave slots take the lean kernel (PTAMD_LEAN_PCT)
     bool deal_dense = true;       // dealt mask walk: the 8-wave build for launches of more than 2 x the device's wave slots (PTAMD_DEAL_DENSE=0: never)
@@ -1008,6 +1012,7 @@ try {
     if (const char *e = getenv("PTAMD_SPLIT_RATIO")) { const int v = atoi(e); if (v >= 1 && v <= 100) d->split_ratio = v; }
     if (const char *e = getenv("PTAMD_SPLIT_PCT")) { const int v = atoi(e); if (v >= 10 && v <= 1000) d->split_pct = v; }
     if (const char *e = getenv("PTAMD_DEAL_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 2 || v == 4 || v == 8) d->deal_split = v; }
+    if (const char *e = getenv("PTAMD_PART_LANES")) d->part_lanes = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_SAH_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) d->sah_split = v; }
     if (const char *e = getenv("PTAMD_SAH_STACK")) { const int v = atoi(e); if (v == 0 || (v >= 11 && v <= 64)) { d->sah_stack_lds = v; d->sah_by_hand = true; } }
     if (const char *e = getenv("PTAMD_LEAN_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 1000) d->lean_pct = v; }
@@ -1446,7 +1451,8 @@ static size_t lds_bytes(const RenderParams &P, int block, bool stage)
     f4 += (size_t)P.top_records * (size_t)(P.top_record_bytes / 16);
     if (P.deal_cap > 0 && P.stack_entries == 0)       // dev::deal_carve (kWalk 4: no stack)
         f4 += (size_t)P.n_tris * 3 /* onb table, stage_shade_lds */ + (size_t)P.n_tris * 3 +
-              (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 2 + 15) / 16);
+              (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 2 + 15) / 16) +
+              (P.part_boxes ? 6 * (size_t)P.n_pairs + (size_t)(block / dev::kWave) * 32 : 0);      // boxes, reach table, ray_c
     if (P.deal_cap > 0 && P.stack_entries != 0)       // dev::deal_carve32 (kWalk 5: stack walk, 32-bit items, no triangle table)
         f4 += (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 4 + 15) / 16 + 3 * (size_t)dev::kStageTris);
     return f4 * 16;
@@ -1476,7 +1482,7 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
         P.spec_pct = dev->spec_pct >= 0 ? dev->spec_pct : (scene_bytes > ((size_t)64 << 20) ? (dev->sah_wide_on ? 50 : 80) : 40);
     }
     P.fold_bits = dev->fold_bits;
-    P.deal_cap = 0; P.deal_min = dev->deal_min; P.any_tex = dev->any_tex ? 1 : 0; P.lrpt = dev->lrpt;
+    P.deal_cap = 0; P.part_boxes = 0; P.deal_min = dev->deal_min; P.any_tex = dev->any_tex ? 1 : 0; P.lrpt = dev->lrpt;
     P.tile_order = nullptr; P.tile_cost = nullptr; P.band_list = nullptr;
     P.legacy_mats = dev->d_legacy; P.spheres = dev->d_spheres; P.n_spheres = dev->n_spheres;
     // SAH walks check for room before they push (SahStack): with the whole stack in LDS the check must never fire, hence + 3
@@ -1614,6 +1620,11 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     const bool dense = (walk == 4 || walk == 5 || (walk == 3 && dev->sah_persistent && dev->sah_wide_on && !dev->sah_quant_on)) && dev->deal_dense &&
                        tiles >= (walk == 4 ? 2ll * dev->max_waves : 2ll * dev->cu_count * 6 * dev::kWavesPerBlock);
     if (dense && walk == 5 && !dev->deal_cap_by_hand) P.deal_cap = 384;      // six workgroups' item lists and stacks in a CU's LDS
+    // Parts of split tiles walk by lanes (part_walk_by_lanes, pt_walk.h) where the tree allows it: all 2 n_pairs hit bits in
+    // one word, every triangle for every ray of a part within the item list.  Only launches that can have parts pay the 1.7 KB of LDS (dense
+    // ones never split, and the eight-wave build has no room for it).
+    P.part_boxes = (walk == 4 && !dense && dev->part_lanes && dev->deal_split >= 2 && dev->deal_split <= 16 && dev->tile_schedule == 1 &&
+                    dev->n_pairs <= 16 && (64ull / (unsigned)dev->deal_split) * dev->n_tris <= (unsigned long long)P.deal_cap) ? 1 : 0;
     // big leaves + stack walk: four waves per tile, each testing a quarter of every leaf (render_kernel_coop)
     // It pays when the launch is small for the machine (a rank's share of a multi-GPU frame): measured on
     // the duck, 1/6 of a 1080p frame and less gains (1/8: 1.85 -> 1.09 s), 1/4 and more loses (whole frame

@@ -58,6 +58,7 @@ struct RenderParams {
     int shade_lds;                    // 1: shade / material / light tables are staged in LDS; 2: material and light tables only
     int deal_cap;                     // dealt walk (kWalk 4): per-wave item list capacity, 0 otherwise
     int deal_min;                     // ... a leaf hit by >= this many lanes of the wave is tested in place
+    int part_boxes;                   // dealt walk: child boxes + reach table staged in LDS, PARTS of split tiles walk by lanes (part_walk_by_lanes)
     int lrpt;                         // dealt kernel: s_setprio by the share of samples still to trace
     int any_tex;                      // some material has a texture: hits need their barycentrics
     int fold_bits;                    // per-lane 32-bit test counters are folded into wider ones at 2^fold_bits (31; tests lower it)

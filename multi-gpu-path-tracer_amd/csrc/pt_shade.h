@@ -196,10 +196,42 @@ __device__ __forceinline__ DealView deal_carve(const RenderParams &P, float4 *ld
     const float4 *gt = reinterpret_cast<const float4 *>(P.tris);
     const int nt = P.n_tris * 3;
     for (int i = tid; i < nt; i += block) lds[i] = gt[i];
-    __syncthreads();
-    D.tris = lds;
     const int wave = tid / kWave;
     const size_t per_wave_f4 = (size_t)kWave + kWave / 2 + kWave / 2 + ((size_t)P.deal_cap * 2 + 15) / 16;
+    D.boxes = nullptr; D.reach = nullptr; D.ray_c = nullptr;
+    if (P.part_boxes) {
+        // For the parts of split tiles (part_walk_by_lanes): behind the waves' areas the workgroup's child boxes, two float4
+        // each, the reach table, and 32 reciprocal directions per wave.
+        float4 *bx = lds + nt + (size_t)(block / kWave) * per_wave_f4;
+        uint4 *rt = reinterpret_cast<uint4 *>(bx + 4 * (size_t)P.n_pairs);
+        const float4 *gn = reinterpret_cast<const float4 *>(P.nodes);
+        for (int p = tid; p < P.n_pairs; p += block) {
+            const float4 a = gn[4 * p], b = gn[4 * p + 1], c = gn[4 * p + 2];
+            bx[4 * p] = a;                                  bx[4 * p + 1] = make_float4(b.x, b.y, 0.0f, 0.0f);
+            bx[4 * p + 2] = make_float4(b.z, b.w, c.x, c.y); bx[4 * p + 3] = make_float4(c.z, c.w, 0.0f, 0.0f);
+        }
+        if (tid == 0) {
+            // reach[b].x = the boxes a ray must hit to enter child box b = 2 * pair + side: b itself and what its pair needs.
+            // Pairs are numbered in visit order, parents first: a pair's own need is left in the .w of its left box by its parent.
+            for (int p = 0; p < P.n_pairs; p++) {
+                const uint32_t pair_need = p == 0 ? 0u : rt[2 * p].w;
+                const uint32_t link[2] = {P.nodes[p].llink, P.nodes[p].rlink}, cnt[2] = {P.nodes[p].lcnt, P.nodes[p].rcnt};
+#pragma unroll
+                for (int side = 0; side < 2; side++) {
+                    const int b = 2 * p + side;
+                    const uint32_t need = pair_need | (1u << b);
+                    rt[b].x = need; rt[b].y = link[side]; rt[b].z = cnt[side];
+                    if (cnt[side] == 0) rt[2 * link[side]].w = need;
+                }
+            }
+        }
+        D.boxes = bx;
+        D.reach = rt;
+        // (the wave index through readfirstlane: a scalar base, so that no per-lane address has to live across the trips)
+        D.ray_c = reinterpret_cast<float4 *>(rt + 2 * (size_t)P.n_pairs) + (size_t)__builtin_amdgcn_readfirstlane(wave) * 32;
+    }
+    __syncthreads();
+    D.tris = lds;
     float4 *w = lds + nt + (size_t)wave * per_wave_f4;
     D.ray_a = w;
     D.keys = reinterpret_cast<unsigned long long *>(w + kWave);

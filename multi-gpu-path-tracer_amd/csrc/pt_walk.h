@@ -276,6 +276,10 @@ struct DealView {
     int cap;                         // item list capacity
     int deal_min;                    // a leaf hit by at least this many lanes is tested in place
     int recompute_uv;                // the scene has textures: barycentrics of a dealt winner are needed
+    // parts of split tiles walk by lanes (part_walk_by_lanes); null when the launch has no parts or the tree does not qualify
+    const float4 *boxes;             // the workgroup's 2 x float4 per child box b = 2 * pair + side: {xmin, xmax, ymin, ymax}, {zmin, zmax, -, -}
+    const uint4 *reach;              // per child box: {boxes a ray must hit to get into it (its own bit included), link, cnt, -}
+    float4 *ray_c;                   // this wave's 32 x {1 / d.x, 1 / d.y, 1 / d.z, -}
 };
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -309,12 +313,86 @@ __device__ __forceinline__ void deal_rounds(const DealView &D, int lane, uint32_
     wave_lds_fence();
 }
 
+// ---- a PART of a split tile walks by lanes ---------------------------------------------------------------------
+// A rank's share of a multi-GPU frame has fewer tiles than the device has wave slots, so its dearest tiles are handed out
+// as parts of 64 / parts pixels each (slot_work, pt_shade.h): the launch then lasts as long as a part's chain of trips, and
+// a trip of the walk above costs a part what it costs a whole tile -- ten pair visits one after the other, each waiting
+// for its scalar loads, with 16 of 64 lanes at work (profiles/r03_lone_part_c2.json).  aabb::hit ignores the ray's
+// interval (aabb.h:38-66), so which boxes a ray hits does not depend on the order of the visits: a part tests ALL child
+// boxes of the tree for its few rays at once, g = 64 / rays lanes per ray, box records and rays from LDS.  From the hit bits
+// a ray enters child box b exactly when it hit b and every box on the way down to it (`reach`, built at staging): the
+// same set of visits as bvh.h:178-246's, hence the same counts; every leaf a ray enters is dealt onto the item list and
+// worked off by deal_rounds as above (min over (t, visit rank) = the reference's in-order update).
+// Needs: n_pairs <= 16 (the hit bits of all 2 n_pairs boxes in 32 bits) and an item list that takes every triangle for every
+// ray of the part (rays x n_tris <= capacity: nothing is worked off in between, which would keep a dozen registers alive
+// across the rounds); the host checks both (launch_render, P.part_boxes).
+__device__ __forceinline__ unsigned long long part_walk_by_lanes(const RenderParams &P, const DealView &D, int lane, bool live, v3 inv, float tmin,
+                                                                 float tmax0, unsigned long long &n_box, unsigned long long &n_tri, int part_lanes)
+{
+    // (the caller has published ray_a / ray_b / keys of every lane)
+    const int g = kWave / part_lanes;                    // lanes per ray = boxes per round: 2 .. 16, wave-uniform
+    const int gs = __builtin_ctz((unsigned)g);
+    // Everything below that depends on the lane alone (ray, box of the round, their LDS addresses) is the same in every trip
+    // of a part: left to itself the compiler computes it once per part and, out of registers, spills it around the trip loop
+    // -- a scratch reload per trip in a chain where latency is everything.  An opaque copy of the lane id keeps it here.
+    int ln = lane;
+    asm volatile("; lane-derived values of part_walk_by_lanes stay in the trip" : "+v"(ln));
+    const int r = ln >> gs, bl = ln & (g - 1);
+    if (ln < part_lanes) D.ray_c[ln] = make_float4(inv.x, inv.y, inv.z, 0.0f);
+    wave_lds_fence();
+    const float4 ra = D.ray_a[r], rc = D.ray_c[r];
+    const v3 ro = mk3(ra.x, ra.y, ra.z), rinv = mk3(rc.x, rc.y, rc.z);
+    const unsigned long long live_mask = pt_ballot(live);
+    const bool ray_live = (live_mask >> r) & 1ull;
+    const int nb = 2 * P.n_pairs;
+    uint32_t bh = 0;                                     // bit b: my ray hits child box b (all g lanes of a ray keep its bits)
+    for (int b0 = 0; b0 < nb; b0 += g) {
+        const int b = b0 + bl;
+        bool hit = false;
+        if (b < nb) {
+            const float4 ba = D.boxes[2 * b], bb = D.boxes[2 * b + 1];
+            hit = box_hit(ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, ro, rinv);
+        }
+        const unsigned long long m = pt_ballot(hit);
+        bh |= ((uint32_t)(m >> (r << gs)) & ((1u << g) - 1u)) << b0;
+    }
+    n_box += 2u * (uint32_t)pt_popc(live_mask);          // the root pair: every live ray tests its two boxes
+    uint32_t n_items = 0;                                // wave-uniform
+    for (int b0 = 0; b0 < nb; b0 += g) {
+        const int b = b0 + bl;
+        uint32_t link = 0, mine = 0;
+        bool inner = false;
+        if (b < nb) {
+            const uint4 q = D.reach[b];
+            const bool in = ray_live & ((bh & q.x) == q.x);
+            link = q.y;
+            mine = in ? q.z : 0u;                        // a leaf's triangles (an inner child has none)
+            inner = in & (q.z == 0u);
+        }
+        n_box += 2u * (uint32_t)pt_popc(pt_ballot(inner));     // the pair behind an inner child: two more boxes
+        // the k-th triangle of every leaf entered in this round, one vote per k
+        for (uint32_t k = 0;; k++) {
+            const unsigned long long mk = pt_ballot(mine > k);
+            if (mk == 0ull) break;
+            const uint32_t n = (uint32_t)pt_popc(mk);
+            if (mine > k) {
+                const uint32_t pos = n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                D.items[pos] = (uint16_t)((uint32_t)r | ((link + k) << 6));
+            }
+            n_items += n;
+            n_tri += n;
+        }
+    }
+    deal_rounds(D, lane, n_items, tmin, tmax0);          // (fences at both ends also when the list is empty)
+    return D.keys[lane];
+}
+
 // Called by ALL 64 lanes of the wave (lanes without a ray pass live = false): the rounds that work the item list off
 // use every lane, whether or not its own pixel still has samples to trace.
 // kInPlace = false: every leaf is dealt (a list that fills up is worked off and reused), no in-place loop is compiled.
 template <bool kInPlace>
 __device__ __forceinline__ Hit traverse_uniform_dealt(const RenderParams &P, const DealView &D, int lane, bool live, v3 o, v3 d, float tmin,
-                                                      float tmax0, unsigned long long &n_box, unsigned long long &n_tri)
+                                                      float tmax0, unsigned long long &n_box, unsigned long long &n_tri, int part_lanes = 0)
 {
     // The closest hit so far is ONE 64-bit key, t bits << 32 | visit rank << 16 | slot, in the in-place loops as in the
     // list: "closer, or as close and visited earlier" is a single unsigned compare, and the lane keeps neither the
@@ -329,7 +407,11 @@ __device__ __forceinline__ Hit traverse_uniform_dealt(const RenderParams &P, con
     uint32_t n_items = 0;                                // wave-uniform
     bool any_items = false;                              // wave-uniform: some test of this segment went through the list
     unsigned long long act = live ? 1ull : 0ull;
-    const int n_pairs = P.n_pairs;
+    const int n_pairs = part_lanes ? 0 : P.n_pairs;      // a part of a split tile (wave-uniform) walks by lanes instead
+    if (part_lanes) {
+        best = part_walk_by_lanes(P, D, lane, live, inv, tmin, tmax0, n_box, n_tri, part_lanes);
+        any_items = false;
+    }
     for (int p = 0; p < n_pairs; p++) {
         const bool on = (act >> p) & 1ull;
         const unsigned long long on_mask = pt_ballot(on);

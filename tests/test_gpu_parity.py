@@ -261,6 +261,34 @@ def test_textures_emissive_texture_and_inheritance_quirk(pt, ob, gpu_device, mod
     assert len(np.unique(ref[0].reshape(-1, 3), axis=0)) > 50         # textured, lit, not flat
 
 
+@pytest.mark.parametrize("parts", [4, 8])
+def test_textured_scene_with_parts_that_walk_by_lanes(pt, ob, gpu_device, monkeypatch, parts):
+    """The textured scene under the dealt mask walk with its dearest tiles split: their parts test all child boxes at once
+    (part_walk_by_lanes) and the winner's barycentrics are recomputed for the texture lookup.  Frames 1-4 (raster order, cost
+    order, split tiles) equal the oracle's, counters included."""
+    monkeypatch.setenv("PTAMD_SPLIT_PCT", "10")
+    monkeypatch.setenv("PTAMD_DEAL_SPLIT", str(parts))
+    tris, mats, texs = _textured_scene(pt)
+    scene = pt.HostScene.from_arrays(tris, mats, texs)
+    osc = ob.OracleScene(tris, mats, texs)
+    cam = ((0.5, 2.0, 7.0), (0.0, 0.0, -1.0), 60.0, 60.0)
+    W, H, spp, depth = 200, 168, 3, 5
+    ref = osc.render(cam, W, H, spp, depth, threads=8)
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, pt.CameraConfig(cam[0], cam[1], cam[2], cam[3]))
+    tr.setTraversalMode(4)
+    seen = 0
+    for frame in range(4):
+        fb.rgb.zero_(); fb.yuv.zero_()
+        tr.resetCounters()
+        tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+        assert "dealt<" in tr.kernelName()
+        _assert_same((fb.rgb_host(), fb.yuv_host(), tr.readCounters()), ref)
+        seen = max(seen, tr.splitTiles())
+    assert seen > 0
+    tr.close()
+
+
 def test_c5_parameters_small_frame(pt, box_scene, box_oracle, gpu_device):
     """BASELINE.json configs[4] parameters (1024 spp, 16 bounces) on a small frame."""
     ref = box_oracle.render(BOX_CAMERA, 32, 16, 1024, 16, threads=8)

@@ -64,14 +64,17 @@ def test_band_tasks_on_several_streams_equal_whole_frame(pt, duck_scene, duck_or
     tr.close()
 
 
-@pytest.mark.parametrize("name,parts", [("box", 2), ("box", 4), ("box", 8), ("duck", 4)])
-def test_dealt_kernel_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, duck_oracle, gpu_device, monkeypatch, name, parts):
+@pytest.mark.parametrize("name,parts,by_lanes", [("box", 2, 1), ("box", 4, 1), ("box", 8, 1), ("box", 4, 0), ("box", 8, 0), ("duck", 4, 1)])
+def test_dealt_kernel_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, duck_oracle, gpu_device, monkeypatch, name, parts, by_lanes):
     """The dealt kernels (mask walk for the box, stack walk for the duck), like the SAH kernel (test_gpu_sah.py), hand the
     dearest tiles of a launch whose longest chain bounds it to several waves of a few pixel rows each.
     PTAMD_SPLIT_PCT = 10 makes that the case on this small frame; every frame -- raster order, cost order, split tiles --
-    must equal the oracle's, counters included."""
+    must equal the oracle's, counters included.  The box's parts of 16 and 8 pixels walk by lanes (part_walk_by_lanes: all
+    child boxes of the tree tested at once, 4 or 8 lanes per ray) unless PTAMD_PART_LANES=0 keeps them on the pair-by-pair
+    walk; its parts of 32 pixels (more (ray, triangle) pairs than the item list holds) and the duck's always are."""
     monkeypatch.setenv("PTAMD_SPLIT_PCT", "10")
     monkeypatch.setenv("PTAMD_DEAL_SPLIT", str(parts))
+    monkeypatch.setenv("PTAMD_PART_LANES", str(by_lanes))
     scene, oracle, cam, kernel = (box_scene, box_oracle, BOX_CAMERA, "dealt<") if name == "box" else (duck_scene, duck_oracle, DUCK_CAMERA, "dealt_stack")
     W, H, spp, depth = (200, 168, 3, 5) if name == "box" else (176, 160, 2, 4)
     fb = pt.Framebuffer(pt.Resolution(W, H))
