@@ -91,11 +91,13 @@ def matching_profile(config, workload, build_id):
     return best
 
 
-def roofline_block(config, workload, cnt, pixels, kernel_ms, launches, kernel_name):
-    """The bound that binds, with the time measured in THIS run (HIP events on the launch stream, pt_kernel_time_read)."""
+def roofline_block(config, workload, cnt, pixels, kernel_ms, launches, kernel_name, device_ms_per_launch=None):
+    """The bound that binds, with the time measured in THIS run (HIP events on the launch stream, pt_kernel_time_read).
+    device_ms_per_launch: frames in flight -- the launches overlap, so the time that goes with one launch's counts is the
+    device time all timed launches took together (first start to last end, HIP events on their streams) / their number."""
     build_id = kernel_build_id()
     prof, path, same_build = matching_profile(config, workload, build_id)
-    per_launch_s = kernel_ms * 1e-3 / max(launches, 1)
+    per_launch_s = (device_ms_per_launch if device_ms_per_launch is not None else kernel_ms / max(launches, 1)) * 1e-3
     alg = algorithmic_bytes(cnt, pixels) / max(launches, 1)
     hbm_bound = config == "c4"         # the only scene (1 GB) that does not live in the scalar cache / L1 / L2
     traffic = lane_instr = None
@@ -123,6 +125,7 @@ def roofline_block(config, workload, cnt, pixels, kernel_ms, launches, kernel_na
                   if prof is not None else "no committed PMC profile of this workload: only the time is measured",
         "kernel_build_id": build_id,
         "kernel": kernel_name, "kernel_ms_avg": kernel_ms / max(launches, 1), "launches": launches,
+        "device_ms_per_launch": device_ms_per_launch if device_ms_per_launch is not None else kernel_ms / max(launches, 1),
         # SURVEY 8(d)'s byte model, kept as a secondary figure: on the KB-sized Cornell scenes these bytes are served by
         # SGPRs / the scalar cache / LDS, never by HBM, so they are NOT divided by the HBM peak
         "algorithmic_hbm_equiv": {
@@ -256,6 +259,9 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on a box with ONE GPU: every rank uses cuda:0 and the exchange runs "
                          "over gloo (RCCL needs one GPU per rank); checks the N > 1 code path, not its speed")
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="frames rendered concurrently, each in its own framebuffer on its own stream: the next frame's waves "
+                         "take the wave slots the current frame's last chains leave idle.  0 = the default (2 for N > 1, 1 on one GPU)")
     ap.add_argument("--share-of", type=int, default=0,
                     help="diagnostic (1 GPU): time only rank 0's row bands of an N-rank split, print a "
                          "diagnostic line instead of the metric line")
@@ -321,8 +327,15 @@ def main():
     bvh = args.bvh or ("sah" if args.config == "c4" else "reference")
     desc += " [bvh=%s]" % bvh
     t_up = time.perf_counter()
+    # Frames in flight (scheduling.py RenderManager): every GPU keeps two frames queued (three from eight ranks on, where a
+    # share is an eighth of a frame and its dearest chains leave the device idle for half of its time), each in its own
+    # framebuffer on its own stream: the next frame's waves take the wave slots the current frame's last chains leave empty
+    # (one GPU, C2: 59.6 -> 55.9 ms per frame; an eighth of C2: 13.7 -> 8.8 ms; profiles/r03_frames_in_flight.json).  The
+    # timed region starts and ends with an empty pipeline.  The cost-fed dealers keep one frame in flight.
+    fif = args.frames_in_flight or ((3 if world >= 8 else 2) if (world == 1 or algo == "fsfl") else 1)
     mgr = pt.RenderManager(cfg, scene, cam, device_idx=local_rank, band_rows=args.band_rows,
-                           bvh_mode=1 if bvh == "sah" else 0)
+                           bvh_mode=1 if bvh == "sah" else 0, frames_in_flight=fif)
+    fif = mgr.frames_in_flight
     upload_s = time.perf_counter() - t_up
     mgr.tracer.setTileSchedule(args.tile_schedule)
     if args.walk:
@@ -332,20 +345,31 @@ def main():
     if args.share_of > 1 and world == 1:
         # what one rank of an N-GPU run computes, measured on this GPU alone (no gather)
         tr = mgr.tracer
-        for _ in range(args.warmup):
-            tr.renderBandsAsync(args.band_rows, args.share_of, 0); tr.waitForRenderTask()
+        F = max(1, args.frames_in_flight)
+        fbs = [mgr.getFramebuffer()] + [pt.Framebuffer(pt.Resolution(W, H), device="cuda:%d" % local_rank) for _ in range(F - 1)]
+        streams = [torch.cuda.Stream(device=local_rank) for _ in range(F)]
+
+        def frames(n):          # n shares, at most F of them in flight: share i waits for share i - F (its framebuffer, its stream)
+            for i in range(n):
+                tr.synchronizeStream(streams[i % F])
+                if F > 1:
+                    tr.setFramebuffer(fbs[i % F])
+                tr.renderBandsAsync(args.band_rows, args.share_of, 0, streams[i % F])
+            for st in streams:
+                tr.synchronizeStream(st)
+        frames(max(args.warmup, F))
         tr.resetCounters(); tr.resetKernelTime()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            tr.renderBandsAsync(args.band_rows, args.share_of, 0); tr.waitForRenderTask()
+        frames(args.steps)
         dt = (time.perf_counter() - t0) / args.steps
         kms, n = tr.kernelTime()
-        print(json.dumps({"diagnostic": "share_of", "n_ranks": args.share_of, "ms_per_share": dt * 1e3,
+        print(json.dumps({"diagnostic": "share_of", "n_ranks": args.share_of, "frames_in_flight": F, "ms_per_share": dt * 1e3,
                           "kernel_ms": kms / n, "segments_per_share": tr.readCounters()["segments"] // args.steps}))
         return
 
     def sync_all():
+        mgr.flush()                    # frames in flight: every launched frame rendered, exchanged and in place on rank 0
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -356,12 +380,17 @@ def main():
     sync_all()
     mgr.tracer.resetCounters()
     mgr.tracer.resetKernelTime()
+    mgr.record_spans = True
+    mgr.resetSpans()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         mgr.renderFrame()
     sync_all()
     elapsed = time.perf_counter() - t0
+    mgr.record_spans = False
+    spans = mgr.launchSpans()          # HIP events on the launches' streams: [(start, end)] relative to the first start
+    device_ms_per_launch = ((max(b for _, b in spans) - min(a for a, _ in spans)) / len(spans)) if spans else None
 
     # max over ranks of the timed region; sum over ranks of the exact work counters
     cnt = mgr.tracer.readCounters()
@@ -398,6 +427,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(n_hv):
             mgr.renderFrame()
+            mgr.flush()                                # one frame at a time here: this is a frame's LATENCY, whatever is in flight above
+            fb = mgr.getFramebuffer()
             if rank == 0:
                 pin_rgb.copy_(fb.rgb, non_blocking=True); pin_yuv.copy_(fb.yuv, non_blocking=True)
                 torch.cuda.synchronize()               # the frame is host-visible here
@@ -419,8 +450,9 @@ def main():
             "config": {"workload": desc, "scene": kind, "width": W, "height": H, "spp": spp, "bounces": depth,
                        "parity": PARITY_NOTE,
                        "tile_schedule": "cost order from the previous frame" if args.tile_schedule else "raster order",
-                       "parallelism": "row-bands x%d (band_rows=%d, dealer=%s), scene replicated, true-size sends to rank 0"
-                                      % (world, args.band_rows, algo if world > 1 else "n/a")},
+                       "parallelism": "row-bands x%d (band_rows=%d, dealer=%s), scene replicated, true-size sends to rank 0, %d frame%s in flight per GPU"
+                                      % (world, args.band_rows, algo if world > 1 else "n/a", fif, "" if fif == 1 else "s")},
+            "frames_in_flight": fif,
             "segments_per_frame": total["segments"] // args.steps,
             "scene_upload_s": upload_s,
             "segments_per_path": total["segments"] / max(total["paths"], 1),
@@ -429,10 +461,18 @@ def main():
             # N > 1: whole-frame counters over the slowest rank's kernel time (per-launch profile counts are those of a
             # whole-frame launch and do not apply to a 1/N share, so `achieved` stays null there)
             "roofline": roofline_block(args.config, desc if world == 1 else desc + " [1/%d shares]" % world, total,
-                                       W * H * args.steps, kernel_ms, launches, mgr.tracer.kernelName()),
+                                       W * H * args.steps, kernel_ms, launches, mgr.tracer.kernelName(),
+                                       device_ms_per_launch if fif > 1 else None),
         }
         if host_visible_ms is not None:
-            out["ms_per_step_host_visible"] = host_visible_ms
+            out["ms_per_step_host_visible"] = host_visible_ms      # one frame at a time, each copied to the host: a frame's latency
+        if fif > 1:
+            out["frames_in_flight_note"] = ("ms_per_step = the timed region (K frames launched, rendered, exchanged; pipeline empty at both "
+                                            "ends) / K with %d frames queued per GPU; ms_per_step_host_visible renders one frame at a time" % fif)
+            out["roofline"]["kernel_ms_note"] = ("launches overlap (%d frames in flight): kernel_ms_avg is a launch's own duration, device_ms_per_launch = "
+                                                 "(last end - first start of the timed launches, HIP events on their streams) / launches is what one "
+                                                 "launch's counts are divided by" % fif)
+            out["launch_spans_ms"] = [[round(a, 3), round(b, 3)] for a, b in spans]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, camera, W, H, spp, depth, args.cpu_rows, kind)
         print(json.dumps(out), flush=True)

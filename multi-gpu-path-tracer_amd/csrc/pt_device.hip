@@ -802,7 +802,7 @@ struct DevBufs {
 // every 8x8 tile cost, a device radix sort turns that into next launch's wave-slot -> tile order
 // (dearest first), so the launch ends on cheap tiles instead of on a straggler that started last.
 struct TileSchedule {
-    int key[9];
+    int key[11];
     unsigned slots = 0;
     void *base = nullptr;         // one stream-ordered allocation, carved into the buffers below
     uint32_t *order = nullptr, *cost = nullptr, *sorted_cost = nullptr, *iota = nullptr;
@@ -1502,7 +1502,11 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
 // cache full of busy entries, or an allocation failed).  Caller holds dev->mu.
 static TileSchedule *schedule_for(pt_device *dev, const RenderParams &P, unsigned slots, hipStream_t hs)
 {
-    const int key[9] = {P.task_w, P.task_h, P.task_ox, P.task_oy, P.band_rows, P.band_ranks, P.band_rank, P.W, P.H};
+    // (the framebuffer is part of the key: a caller that keeps two frames in flight, each in its own framebuffer on its own
+    // stream, gets a schedule per framebuffer -- launches that share one are ordered behind each other, see launch_render)
+    const unsigned long long fb_bits = (unsigned long long)(uintptr_t)P.rgb;
+    const int key[11] = {P.task_w, P.task_h, P.task_ox, P.task_oy, P.band_rows, P.band_ranks, P.band_rank, P.W, P.H,
+                         (int)(uint32_t)fb_bits, (int)(uint32_t)(fb_bits >> 32)};
     dev->schedule_clock++;
     for (TileSchedule *t : dev->schedules)
         if (memcmp(t->key, key, sizeof key) == 0 && t->slots == slots) { t->stamp = dev->schedule_clock; return t; }

@@ -288,9 +288,15 @@ class RenderManager:
     (lpt_assignment).  Images are identical under every dealer.
     """
 
+    frames_in_flight = 1          # (class defaults: one frame at a time, nothing in flight)
+    frames_completed = 0
+    _inflight = ()
+    record_spans = False          # bench.py: a pair of timing events around every frame's launch, on the launch's stream
+
     def __init__(self, config: RendererConfig, hScene: HostScene, cameraConfig: CameraConfig,
                  device_idx: int = 0, band_rows: int = 8, streams_per_gpu: Optional[int] = None,
-                 bvh_mode: int = 0):
+                 bvh_mode: int = 0, frames_in_flight: int = 1):
+        import collections
         import torch
         import torch.distributed as dist
         self._torch = torch
@@ -307,6 +313,26 @@ class RenderManager:
                                        bvhMode=bvh_mode)        # 1 = opt-in SAH tree (not the reference's traversal)
         n_streams = streams_per_gpu or config.streamsPerGpu
         self.streams = [torch.cuda.Stream(device=device_idx) for _ in range(max(1, n_streams))]
+        # FRAMES IN FLIGHT (no counterpart in the reference, whose renderFrame ends on a barrier, RenderManager.h:410-431).
+        # A rank's share of a frame has fewer tiles than its GPU has wave slots and lasts as long as its dearest pixels'
+        # chains of dependent trips (a pixel's samples are one RNG stream): for most of that time most of the device idles.
+        # With F > 1 renderFrame() launches frame i and then completes frame i - F + 1: up to F launches are queued on the
+        # device, each in its own framebuffer on its own stream (the library keeps a tile schedule per framebuffer), and the
+        # waves of the younger ones take the slots the oldest one's last chains leave empty.  A frame's latency grows, the
+        # frame rate approaches what the work allows (an eighth of C2: 13.7 ms per frame alone, 10.3 / 8.8 ms with 2 / 3 in
+        # flight; profiles/r03_frames_in_flight.json).  F + 1 framebuffers form a ring, so the last COMPLETE frame
+        # (getFramebuffer / getCurrentFrame) stays untouched until the next renderFrame().  Images are the same frames in the
+        # same order.  The cost-fed dealers (DSFL / DSDL) re-deal between consecutive frames and keep one frame in flight.
+        self.frames_in_flight = max(1, int(frames_in_flight))
+        if self.dynamic():
+            self.frames_in_flight = 1
+        self._inflight = collections.deque()      # (framebuffer, stream) of launched, not yet completed frames, oldest first
+        self._launched = 0
+        self.frames_completed = 0                 # frames in flight: how many frames have been completed so far
+        if self.frames_in_flight > 1:
+            self._ring = [self.framebuffer_] + [Framebuffer(config.resolution, device="cuda:%d" % device_idx)
+                                                for _ in range(self.frames_in_flight)]
+            self.streams = [torch.cuda.Stream(device=device_idx) for _ in range(self.frames_in_flight)]
         self._make_tasks()
         self.last_frame_ms = 0.0
 
@@ -344,7 +370,11 @@ class RenderManager:
         self.tracer.setRecursionDepth(depth)
 
     def setResolution(self, res: Resolution):
+        self.flush()
         self.config_.resolution = res
+        if self.frames_in_flight > 1:
+            for fb in self._ring:
+                fb.setResolution(res)
         self.framebuffer_.setResolution(res)
         self.tracer.setFramebuffer(self.framebuffer_)
         self._make_tasks()
@@ -352,15 +382,41 @@ class RenderManager:
     def getFramebuffer(self) -> Framebuffer:
         return self.framebuffer_
 
-    def renderTasks(self):
+    def resetSpans(self):
+        self._spans = []
+
+    def launchSpans(self):
+        """[(start_ms, end_ms)] of every frame launched since resetSpans() with record_spans on, relative to the first one's
+        start, from HIP events recorded on the launches' own streams (call after flush() / a device synchronisation).  With
+        frames in flight the launches overlap: the device time they took TOGETHER is max(end) - min(start)."""
+        spans = getattr(self, "_spans", [])
+        if not spans:
+            return []
+        base = spans[0][0]
+        return [(base.elapsed_time(a), base.elapsed_time(b)) for a, b in spans]
+
+    def renderTasks(self, stream=None):
         """Launch this rank's share of the frame (StreamThread::threadMain, StreamThread.h:83-84):
         ONE kernel launch covering all of its row bands."""
-        if self.world == 1:
-            self.tracer.renderTaskAsync(self.renderTasks_[0], self.streams[0])
-        elif self.static_:
-            self.tracer.renderBandsAsync(self.band_rows, self.world, self.rank, self.streams[0])
+        stream = stream if stream is not None else self.streams[0]
+        if self.record_spans and stream is not None:
+            a, b = self._torch.cuda.Event(enable_timing=True), self._torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            self._launch(stream)
+            b.record(stream)
+            if not hasattr(self, "_spans"):
+                self._spans = []
+            self._spans.append((a, b))
         else:
-            self.tracer.renderBandListAsync(self.band_rows, self.assignment_[self.rank], self.streams[0])
+            self._launch(stream)
+
+    def _launch(self, stream):
+        if self.world == 1:
+            self.tracer.renderTaskAsync(self.renderTasks_[0], stream)
+        elif self.static_:
+            self.tracer.renderBandsAsync(self.band_rows, self.world, self.rank, stream)
+        else:
+            self.tracer.renderBandListAsync(self.band_rows, self.assignment_[self.rank], stream)
 
     def synchronize(self):
         for s in self.streams:
@@ -398,8 +454,46 @@ class RenderManager:
             self.static_ = False
             self._refresh_tasks()
 
+    def _complete_oldest(self, gather: bool):
+        """Frames in flight: wait for the oldest launched frame, run its exchange, make it the current frame."""
+        fb, stream = self._inflight.popleft()
+        self.tracer.synchronizeStream(stream)
+        if gather and self.world > 1:
+            res = self.config_.resolution
+            exchange = BandGather(res.width, res.height, self.band_rows, self.assignment_, fb.rgb)
+            packed = pack_rank_bands(fb.rgb, fb.yuv, res.width, res.height, self.band_rows, self.assignment_[self.rank],
+                                     self._torch)
+            exchange.finish(packed, fb.rgb, fb.yuv)       # every rank: frames in launch order, one batch per frame
+        self.framebuffer_ = fb
+        self.frames_completed += 1
+
+    def flush(self, gather: bool = True):
+        """Frames in flight: complete every launched frame, oldest first (no-op otherwise).  Afterwards
+        getFramebuffer() / getCurrentFrame() is the last frame launched."""
+        while self._inflight:
+            self._complete_oldest(gather)
+
+    def _render_frame_in_flight(self, gather: bool):
+        torch = self._torch
+        F = self.frames_in_flight
+        fb = self._ring[self._launched % (F + 1)]
+        stream = self.streams[self._launched % F]
+        # whatever read or unpacked this buffer last (the current stream's work) is done before the kernel writes to it
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream(fb.rgb.device))
+        self.tracer.setFramebuffer(fb)
+        self.renderTasks(stream)
+        self._inflight.append((fb, stream))
+        self._launched += 1
+        if len(self._inflight) >= F:
+            self._complete_oldest(gather)
+
     def renderFrame(self, gather: bool = True):
         t0 = time.perf_counter()
+        if self.frames_in_flight > 1:
+            self._render_frame_in_flight(gather)
+            self.last_frame_ms = (time.perf_counter() - t0) * 1e3
+            return
         res = self.config_.resolution
         if self._pending_costs is not None:
             self._finish_redeal()                 # this frame's split, from the previous frame's costs
@@ -429,6 +523,7 @@ class RenderManager:
         return self.framebuffer_.yuv_host()
 
     def reset(self):
+        self.flush(gather=False)
         if self._pending_costs is not None:
             self._pending_costs[1].wait()
             self._pending_costs = None

@@ -130,6 +130,9 @@ class _FakeTracer:
     def synchronizeStream(self, s):
         pass
 
+    def setFramebuffer(self, fb):
+        self.fb = fb
+
     def bandCosts(self):
         return [self.costs[b] for b in self.last]
 
@@ -192,6 +195,78 @@ def _order_worker(rank, world, port, W, H, band, out_dir):
     open(os.path.join(out_dir, "order_%d.txt" % rank), "w").write(repr(frames))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _in_flight_worker(rank, world, port, W, H, band, fif, out_dir):
+    """RenderManager with frames in flight (fixed split), orchestration only: every rank issues one point-to-point batch per
+    COMPLETED frame, in launch order, and nothing else; every complete frame rank 0 hands out is whole; a ring buffer is
+    not written again before the frame after the one it was handed out in."""
+    import collections
+    sys.path.insert(0, ROOT)
+    pt = importlib.import_module(PKG)
+    sched = importlib.import_module(PKG + ".scheduling")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+    real_batch = dist.batch_isend_irecv
+
+    def batch(ops):
+        log.append("p2p")
+        return real_batch(ops)
+
+    dist.batch_isend_irecv = batch
+    total = W * H
+    rng = np.random.default_rng(7)
+    ref_rgb = torch.from_numpy(rng.integers(0, 256, total * 3, dtype=np.uint8))
+    ref_yuv = torch.from_numpy(rng.integers(0, 256, total + 2 * (total // 4), dtype=np.uint8))
+    n_bands = (H + band - 1) // band
+    mgr = object.__new__(sched.RenderManager)              # the orchestration only: no GPU, no DevicePathTracer
+    mgr._torch = torch
+    mgr.config_ = pt.RendererConfig(samplesPerPixel=1, recursionDepth=1, gpuNumber=world, resolution=pt.Resolution(W, H),
+                                    showTasks=False, algorithmType=pt.FSFL)
+    mgr.rank, mgr.world, mgr.band_rows = rank, world, band
+    mgr.frames_in_flight, mgr.streams, mgr._inflight, mgr._launched = fif, [None] * fif, collections.deque(), 0
+    mgr._ring = []
+    for _ in range(fif + 1):
+        fb = _FakeFb()
+        fb.rgb, fb.yuv = torch.zeros_like(ref_rgb), torch.zeros_like(ref_yuv)
+        mgr._ring.append(fb)
+    mgr.framebuffer_ = mgr._ring[0]
+    mgr.tracer = _FakeTracer(pt, ref_rgb, ref_yuv, mgr._ring[0], W, H, band, _costs(n_bands, 11))
+    mgr._make_tasks()
+    calls, handed = [], 0
+    for frame in range(2 * fif + 3):
+        log.clear()
+        done = mgr.frames_completed
+        mgr.renderFrame()
+        calls.append(list(log))
+        assert mgr.frames_completed - done == (1 if frame >= fif - 1 else 0)
+        if rank == 0 and mgr.frames_completed > done:
+            cur = mgr.getFramebuffer()
+            assert cur is mgr._ring[(frame - fif + 1) % (fif + 1)]
+            assert torch.equal(cur.rgb, ref_rgb) and torch.equal(cur.yuv, ref_yuv), "frame %d" % frame
+            cur.rgb.zero_(); cur.yuv.zero_()               # the next frame in this buffer must be rendered and exchanged afresh
+            handed += 1
+    log.clear()
+    mgr.flush()
+    calls.append(list(log))
+    assert mgr.frames_completed == 2 * fif + 3 and not mgr._inflight
+    if rank == 0:
+        cur = mgr.getFramebuffer()
+        assert torch.equal(cur.rgb, ref_rgb) and torch.equal(cur.yuv, ref_yuv)
+    open(os.path.join(out_dir, "calls_%d.txt" % rank), "w").write(repr(calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fif", [(2, 2), (3, 3)])
+def test_frames_in_flight_exchange_one_batch_per_completed_frame_in_order(tmp_path, world, fif):
+    mp.spawn(_in_flight_worker, args=(world, _free_port(), 64, 72, 8, fif, str(tmp_path)), nprocs=world, join=True)
+    calls = [eval((tmp_path / ("calls_%d.txt" % r)).read_text()) for r in range(world)]
+    want = [[] if f < fif - 1 else ["p2p"] for f in range(2 * fif + 3)] + [["p2p"] * (fif - 1)]
+    for r in range(world):
+        assert calls[r] == want, (r, calls[r], want)
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -202,6 +202,73 @@ def _rank_worker(rank, world, port, W, H, spp, depth, band, out_path, algo=0, fr
     dist.destroy_process_group()
 
 
+def _rank_worker_in_flight(rank, world, port, W, H, spp, depth, band, out_path, fif):
+    import importlib
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    pt = importlib.import_module("multi-gpu-path-tracer_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = pt.SceneLoader().load(os.path.join(ROOT, "models", "cornell_box.glb")).applyCornellConvention()
+    cfg = pt.RendererConfig(samplesPerPixel=spp, recursionDepth=depth, gpuNumber=world,
+                            resolution=pt.Resolution(W, H), showTasks=False, algorithmType=pt.FSFL)
+    mgr = pt.RenderManager(cfg, scene, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]), device_idx=0, band_rows=band,
+                           frames_in_flight=fif)
+    assert mgr.frames_in_flight == fif and len(mgr._ring) == fif + 1
+    frames, complete = 2 * fif + 3, []
+    for i in range(frames):
+        if i == fif + 2:                       # every buffer of the ring has held a frame by now: wipe them (after a flush, so
+            mgr.flush()                        # that nothing in flight is touched) -- what is read from here on was rendered from here on
+            for fb in mgr._ring:
+                fb.rgb.zero_(); fb.yuv.zero_()
+            torch.cuda.synchronize()
+        done = mgr.frames_completed
+        mgr.renderFrame()
+        if rank == 0 and mgr.frames_completed > done:      # a frame was completed: it stays readable until the next renderFrame()
+            complete.append(mgr.getCurrentFrame().copy())
+    mgr.flush()
+    cnt = mgr.tracer.readCounters()
+    tot = torch.tensor([float(cnt["segments"])], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tot)
+    if rank == 0:
+        ring = np.stack([fb.rgb_host() for fb in mgr._ring])
+        np.savez(out_path, rgb=mgr.getCurrentFrame(), yuv=mgr.getYUVFrame(), segments=np.array([tot.item() / frames]),
+                 complete=np.stack(complete), ring=ring)
+    if world > 1:
+        dist.barrier()
+    mgr.reset()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fif,W,H,band", [(2, 2, 96, 64, 8), (3, 3, 64, 40, 8), (1, 2, 96, 64, 8)])
+def test_frames_in_flight_render_the_same_frames(box_oracle, gpu_device, tmp_path, world, fif, W, H, band):
+    """RenderManager(frames_in_flight = F): renderFrame() launches frame i and completes frame i - F + 1, F launches queued
+    per GPU, each in its own buffer of a ring of F + 1 on its own stream, the exchange per frame in launch order.  Every
+    complete frame handed out is the oracle's, every ring buffer is rendered afresh (they are wiped mid-run), the ranks'
+    segments add up to frames x the oracle's.  World 1 too: one process, no exchange."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "frame.npz")
+    spp, depth = 3, 4
+    mp.spawn(_rank_worker_in_flight, args=(world, port, W, H, spp, depth, band, out, fif), nprocs=world, join=True)
+    got = np.load(out)
+    ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
+    assert np.array_equal(got["rgb"], ref[0]) and np.array_equal(got["yuv"], ref[1])
+    for k, img in enumerate(got["complete"]):
+        assert np.array_equal(img, ref[0]), "complete frame %d differs from the oracle" % k
+    assert len(got["complete"]) == 5            # 3 before the mid-run flush, 2 after it; the flushes complete the others
+    for k, img in enumerate(got["ring"]):
+        assert np.array_equal(img, ref[0]), "ring buffer %d was not rendered afresh" % k
+    assert int(got["segments"][0]) == ref[2]["segments"]
+
+
 @pytest.mark.parametrize("world,W,H,band", [(2, 96, 64, 8), (3, 64, 36, 8)])
 def test_multi_rank_render_manager_frame_equals_oracle(box_oracle, gpu_device, tmp_path, world, W, H, band):
     """The N > 1 path end to end on real kernels: `world` processes (all on this box's one GPU,
