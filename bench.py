@@ -259,7 +259,7 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on a box with ONE GPU: every rank uses cuda:0 and the exchange runs "
                          "over gloo (RCCL needs one GPU per rank); checks the N > 1 code path, not its speed")
-    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3],
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="frames rendered concurrently, each in its own framebuffer on its own stream: the next frame's waves "
                          "take the wave slots the current frame's last chains leave idle.  0 = the default (2 for N > 1, 1 on one GPU)")
     ap.add_argument("--share-of", type=int, default=0,

@@ -124,7 +124,9 @@ PT_API pt_status pt_upload_scene_strided(pt_device *dev, const void *triangles, 
                                          const pt_texture *textures, size_t n_textures);
 /* setFramebuffer(), DevicePathTracer.h:342-358: rgb = 3*w*h bytes, yuv = w*h + 2*(w*h/4)
  * bytes (Framebuffer.h:27-35), both device-accessible.  No RNG table is allocated: the
- * per-pixel XORWOW state of render_init (DevicePathTracer.h:46-55) is re-derived in-kernel. */
+ * per-pixel XORWOW state of render_init (DevicePathTracer.h:46-55) is re-derived in-kernel.
+ * Cheap (no synchronisation): a launch renders into the buffers bound when it was enqueued, so
+ * rebinding between launches is how several frames are kept in flight.                       */
 PT_API pt_status pt_bind_framebuffer(pt_device *dev, int width, int height,
                                      uint8_t *rgb_device, uint8_t *yuv_device);
 /* setThreadBlockSize(dim3), DevicePathTracer.h:368: a hint (pixel-tile shape per wave). */
@@ -167,7 +169,12 @@ PT_API pt_status pt_set_cooperative_mode(pt_device *dev, int mode);
  * frame-to-frame feedback (DSFL/DSDL adapt task rectangles from last frame's task times,
  * RenderManager.h:264-408) applied inside one GPU at tile granularity.  Pixels never depend on the
  * order (per-pixel seeds), so images are byte-identical in both modes.  Up to 16 task geometries
- * are tracked per device; launches of fewer than 256 tiles always use raster order.          */
+ * are tracked per device; launches of fewer than 256 tiles always use raster order.
+ * A schedule belongs to (task geometry, bound framebuffer): launches that share one are ordered
+ * behind each other, so a caller that keeps several FRAMES IN FLIGHT -- pt_bind_framebuffer to
+ * another buffer, launch on another stream -- gets one schedule per buffer and launches that
+ * overlap on the device (the younger frame's waves take the wave slots the older frame's last
+ * tiles leave idle; scheduling.py RenderManager(frames_in_flight=...)).                      */
 PT_API pt_status pt_set_tile_schedule(pt_device *dev, int mode);
 
 /* Traversal schedule of the render kernel (same results and test counts, different order of
