@@ -183,16 +183,31 @@ def unpack_bands_strided(packed, rgb_flat, yuv_flat, width: int, height: int, ba
     return pos
 
 
+_BAND_INDEX_CACHE = {}
+
+
+def _band_index(bands, device):
+    """The band list as an index tensor on `device`, made once per (list, device): building it is a blocking host-to-device
+    copy, and with the fixed split the same eight lists come back every frame (rank 0 unpacks N - 1 of them per frame)."""
+    import torch
+    key = (tuple(int(b) for b in bands), str(device))
+    idx = _BAND_INDEX_CACHE.get(key)
+    if idx is None:
+        if len(_BAND_INDEX_CACHE) >= 256:              # cost-fed dealers make new lists every frame: keep the table small
+            _BAND_INDEX_CACHE.clear()
+        idx = _BAND_INDEX_CACHE[key] = torch.as_tensor(list(key[0]), dtype=torch.long, device=device)
+    return idx
+
+
 def pack_bands_indexed(rgb_flat, yuv_flat, width: int, height: int, band_rows: int, bands):
     """pack_bands for torch tensors and an arbitrary band list when uniform_bands(): four row selections."""
     import torch
-    idx = torch.as_tensor(list(bands), dtype=torch.long, device=rgb_flat.device)
+    idx = _band_index(bands, rgb_flat.device)
     return torch.cat([p.index_select(0, idx).reshape(-1) for p in _plane_views(rgb_flat, yuv_flat, width, height, band_rows)])
 
 
 def unpack_bands_indexed(packed, rgb_flat, yuv_flat, width: int, height: int, band_rows: int, bands):
-    import torch
-    idx = torch.as_tensor(list(bands), dtype=torch.long, device=rgb_flat.device)
+    idx = _band_index(bands, rgb_flat.device)
     pos = 0
     for p in _plane_views(rgb_flat, yuv_flat, width, height, band_rows):
         n = len(bands) * p.shape[1]
@@ -461,8 +476,9 @@ class RenderManager:
         if gather and self.world > 1:
             res = self.config_.resolution
             exchange = BandGather(res.width, res.height, self.band_rows, self.assignment_, fb.rgb)
-            packed = pack_rank_bands(fb.rgb, fb.yuv, res.width, res.height, self.band_rows, self.assignment_[self.rank],
-                                     self._torch)
+            # (rank 0's own bands are in place already: only the peers pack)
+            packed = None if self.rank == 0 else pack_rank_bands(fb.rgb, fb.yuv, res.width, res.height, self.band_rows,
+                                                                 self.assignment_[self.rank], self._torch)
             exchange.finish(packed, fb.rgb, fb.yuv)       # every rank: frames in launch order, one batch per frame
         self.framebuffer_ = fb
         self.frames_completed += 1
@@ -504,8 +520,8 @@ class RenderManager:
         self.renderTasks()
         self.synchronize()
         if exchange is not None:
-            packed = pack_rank_bands(self.framebuffer_.rgb, self.framebuffer_.yuv, res.width, res.height,
-                                     self.band_rows, self.assignment_[self.rank], self._torch)
+            packed = None if self.rank == 0 else pack_rank_bands(self.framebuffer_.rgb, self.framebuffer_.yuv, res.width, res.height,
+                                                                 self.band_rows, self.assignment_[self.rank], self._torch)
             exchange.finish(packed, self.framebuffer_.rgb, self.framebuffer_.yuv)
         # ORDER MATTERS on RCCL: point-to-point batches and collectives of one process group share one communicator and
         # one stream, so every rank must enqueue them in the same order -- the frame's exchange first (rank 0's grouped
