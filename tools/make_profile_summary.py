@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, cfg = sys.argv[1], sys.argv[2]
 variant = sys.argv[3] if len(sys.argv) > 3 else tag
 out_dir = os.path.join(ROOT, "profiles")
+stem = tag if tag.endswith("_" + cfg) else "%s_%s" % (tag, cfg)       # tools/r03_final.sh tags its runs <round>_<cfg> already
 go = os.path.join(ROOT, "gpurun_out")
 
 
@@ -27,10 +28,10 @@ def one(pattern):
 # 1. kernel stats + trace rows
 stats = one(os.path.join(go, "prof_%s" % tag, "**", "*_kernel_stats.csv"))
 trace = one(os.path.join(go, "prof_%s" % tag, "**", "*_kernel_trace.csv"))
-open(os.path.join(out_dir, "%s_%s_kernel_stats.csv" % (tag, cfg)), "w").write(open(stats).read())
+open(os.path.join(out_dir, "%s_kernel_stats.csv" % stem), "w").write(open(stats).read())
 rows = list(csv.reader(open(trace)))
 hdr, body = rows[0], [r for r in rows[1:] if any("render_kernel" in c for c in r)]
-with open(os.path.join(out_dir, "%s_%s_kernel_trace_rows.csv" % (tag, cfg)), "w", newline="") as f:
+with open(os.path.join(out_dir, "%s_kernel_trace_rows.csv" % stem), "w", newline="") as f:
     w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
     w.writerow(hdr)
     w.writerows(body)
@@ -100,5 +101,5 @@ if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
         "simd_issue_busy_frac": c["SQ_INSTS_VALU"] * 2.0 / (256 * 4 * derived.get("clock_ghz", 2.4) * 1e9 * kernel_s),
         "note": "peak = 256 CUs x 4 SIMD-32 x 2.4 GHz; one wave64 VALU instruction occupies a SIMD for 2 cycles "
                 "(MI355X_MICROARCH.md); every instruction here is a single IEEE op (no FMA contraction by contract)"}
-json.dump(summary, open(os.path.join(out_dir, "%s_%s_pmc_summary.json" % (tag, cfg)), "w"), indent=1)
+json.dump(summary, open(os.path.join(out_dir, "%s_pmc_summary.json" % stem), "w"), indent=1)
 print(json.dumps({k: summary[k] for k in ("kernel", "kernel_trace_ms", "hbm_bytes_per_launch", "derived", "valu_roofline") if k in summary}, indent=1))
