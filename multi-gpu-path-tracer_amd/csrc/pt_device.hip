@@ -1627,8 +1627,11 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     // Parts of split tiles walk by lanes (part_walk_by_lanes, pt_walk.h) where the tree allows it: all 2 n_pairs hit bits in
     // one word, every triangle for every ray of a part within the item list.  Only launches that can have parts pay the 1.7 KB of LDS (dense
     // ones never split, and the eight-wave build has no room for it).
+    // (an unsplit root is its own two children, bvh.h:26: every ray then lists the root's triangles twice)
+    const unsigned long long lists_per_tri = (!dev->bvh.nodes.empty() && dev->bvh.nodes[0].triCount != 0) ? 2ull : 1ull;
     P.part_boxes = (walk == 4 && !dense && dev->part_lanes && dev->deal_split >= 2 && dev->deal_split <= 16 && dev->tile_schedule == 1 &&
-                    dev->n_pairs <= 16 && (64ull / (unsigned)dev->deal_split) * dev->n_tris <= (unsigned long long)P.deal_cap) ? 1 : 0;
+                    dev->n_pairs >= 1 && dev->n_pairs <= 16 &&
+                    (64ull / (unsigned)dev->deal_split) * lists_per_tri * dev->n_tris <= (unsigned long long)P.deal_cap) ? 1 : 0;
     // big leaves + stack walk: four waves per tile, each testing a quarter of every leaf (render_kernel_coop)
     // It pays when the launch is small for the machine (a rank's share of a multi-GPU frame): measured on
     // the duck, 1/6 of a 1080p frame and less gains (1/8: 1.85 -> 1.09 s), 1/4 and more loses (whole frame

@@ -506,10 +506,12 @@ class RenderManager:
 
     def renderFrame(self, gather: bool = True):
         t0 = time.perf_counter()
-        if self.frames_in_flight > 1:
+        if self.frames_in_flight > 1 and not self.dynamic():
             self._render_frame_in_flight(gather)
             self.last_frame_ms = (time.perf_counter() - t0) * 1e3
             return
+        if self._inflight:                        # a cost-fed dealer was switched on with frames in flight: finish them, then
+            self.flush(gather)                    # one frame at a time (the last frame launched is the bound framebuffer)
         res = self.config_.resolution
         if self._pending_costs is not None:
             self._finish_redeal()                 # this frame's split, from the previous frame's costs

@@ -289,6 +289,41 @@ def test_textured_scene_with_parts_that_walk_by_lanes(pt, ob, gpu_device, monkey
     tr.close()
 
 
+@pytest.mark.parametrize("parts,cap", [(4, 64), (2, 64), (8, 768)])
+def test_unsplit_root_scene_with_split_tiles(pt, ob, gpu_device, monkeypatch, parts, cap):
+    """Two triangles: the reference's root stays a leaf and is its own two children (bvh.h:26), so every ray lists its
+    triangles twice.  With the dearest tiles split, parts of 16 pixels and a 64-entry item list the list is exactly full
+    (16 rays x 2 triangles x 2) and the parts walk by lanes; parts of 32 pixels would overflow it and keep the pair walk.
+    Frames 1-4 equal the oracle's, counters included."""
+    monkeypatch.setenv("PTAMD_SPLIT_PCT", "10")
+    monkeypatch.setenv("PTAMD_DEAL_SPLIT", str(parts))
+    monkeypatch.setenv("PTAMD_DEAL_CAP", str(cap))
+    tris = np.zeros(2, pt.capi.TRIANGLE_DTYPE)
+    for k, (a, b, c, m) in enumerate([((-6, 0, -6), (6, 0, 6), (6, 0, -6), 0), ((-2, 4, -2), (2, 4, -2), (0, 4, 2), 1)]):
+        for name, pos in (("v0", a), ("v1", b), ("v2", c)):
+            tris[k][name]["position"] = pos
+        tris[k]["materialIdx"] = m
+    mats = np.zeros(2, pt.capi.MATERIAL_DTYPE)
+    mats["baseColorTextureIdx"] = -1; mats["emissiveTextureIdx"] = -1
+    mats[0]["baseColor"] = (0.7, 0.6, 0.5)
+    mats[1]["emissiveFactor"] = (1.0, 0.9, 0.8)
+    scene = pt.HostScene.from_arrays(tris, mats, [])
+    osc = ob.OracleScene(tris, mats, [])
+    cam = ((0.0, 2.0, 9.0), (0.0, -0.1, -1.0), 60.0, 60.0)
+    W, H, spp, depth = 200, 168, 3, 5
+    ref = osc.render(cam, W, H, spp, depth, threads=8)
+    assert ref[2]["tri_tests"] % 4 == 0 and ref[2]["tri_tests"] > 0      # both triangles, through both "children", per box hit
+    fb = pt.Framebuffer(pt.Resolution(W, H))
+    tr = pt.DevicePathTracer(0, spp, depth, (8, 8), scene, fb, pt.CameraConfig(cam[0], cam[1], cam[2], cam[3]))
+    tr.setTraversalMode(4)
+    for frame in range(4):
+        fb.rgb.zero_(); fb.yuv.zero_()
+        tr.resetCounters()
+        tr.renderTaskAsync(pt.RenderTask(W, H, 0, 0)); tr.waitForRenderTask()
+        _assert_same((fb.rgb_host(), fb.yuv_host(), tr.readCounters()), ref)
+    tr.close()
+
+
 def test_c5_parameters_small_frame(pt, box_scene, box_oracle, gpu_device):
     """BASELINE.json configs[4] parameters (1024 spp, 16 bounces) on a small frame."""
     ref = box_oracle.render(BOX_CAMERA, 32, 16, 1024, 16, threads=8)

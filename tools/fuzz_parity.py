@@ -65,6 +65,8 @@ def one(seed):
     os.environ["PTAMD_SCHED_MIN_BLOCKS"] = str(int(rng.choice([1, 2, 64])))
     os.environ["PTAMD_SPLIT_PCT"] = str(int(rng.choice([10, 90])))
     os.environ["PTAMD_SAH_SPLIT"] = str(int(rng.choice([0, 4, 16, 64])))
+    os.environ["PTAMD_DEAL_SPLIT"] = str(int(rng.choice([4, 4, 8, 2])))     # dealt kernels: waves per split tile ...
+    os.environ["PTAMD_PART_LANES"] = str(int(rng.choice([1, 1, 0])))        # ... whose parts walk by lanes where the tree allows it
     os.environ["PTAMD_SAH_WIDE"] = str(int(rng.choice([0, 1, 1])))          # the SAH tree's device form: pairs or 4-wide nodes
     os.environ["PTAMD_SAH_QUANT"] = str(int(rng.choice([0, 1])))            # ... in 128-byte or in 64-byte (quantised) records
     os.environ["PTAMD_SAH_STACK"] = str(int(rng.choice([0, 11, 16])))       # ... with the whole stack in LDS or a short one + overflow area
