@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 : > gpurun_out/exp_c4.txt
 for v in ${VALS:-0}; do
   for cfg in "--config c4" "--config c3 --bvh sah"; do
-    r=$(env $VAR=$v timeout -k 10 300 python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-host-visible $cfg 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('%.2f ms  %s' % (d['roofline']['kernel_ms_avg'], d['roofline']['kernel']))")
+    r=$(env $VAR=$v timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-host-visible $cfg 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('%.2f ms per frame (%d in flight)  %s' % (d['ms_per_step'], d['frames_in_flight'], d['roofline']['kernel']))")
     echo "$cfg $VAR=$v: $r" | tee -a gpurun_out/exp_c4.txt
   done
 done
