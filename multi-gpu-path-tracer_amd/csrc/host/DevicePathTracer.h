@@ -4,6 +4,9 @@
 #pragma once
 
 #include <memory>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #include "../../../include/pt_amd.h"
 #include "Framebuffer.h"
@@ -60,6 +63,42 @@ public:
         checkPtErrors(pt_fb_download_task(dev_, &t, framebuffer_->getRGBPtr(), framebuffer_->getYUVPtr(), stream));
     }
 
+    // ---- frames in flight (RendererConfig::framesInFlight > 1; no counterpart in the reference, whose renderFrame ends on
+    // a barrier).  A launch renders into the device framebuffer bound when it was enqueued and pt_bind_framebuffer is a
+    // pointer swap, so frame i goes into slot i % (F + 1) of a ring of device framebuffers while frame i - F + 1 is copied
+    // out of its own slot; the library keeps one tile schedule per framebuffer, so launches into different slots overlap.
+    // The workers of one GPU share the engine's binding: bind + launch and bind + copy are atomic under bindMu_.
+    void setFramesInFlight(unsigned frames)
+    {
+        std::lock_guard<std::mutex> lk(bindMu_);
+        for (size_t i = 1; i < ring_.size(); i++) pt_fb_free(dev_, ring_[i].first, ring_[i].second);
+        ring_.assign(1, {d_rgb_, d_yuv_});
+        Resolution r = framebuffer_->getResolution();
+        for (unsigned i = 0; frames > 1 && i < frames; i++) {
+            uint8_t *rgb = nullptr, *yuv = nullptr;
+            checkPtErrors(pt_fb_alloc(dev_, (int)r.width, (int)r.height, &rgb, &yuv));
+            ring_.push_back({rgb, yuv});
+        }
+    }
+    size_t ringSize() const { return ring_.size(); }
+    void bindSlot(size_t slot)
+    {
+        std::lock_guard<std::mutex> lk(bindMu_);
+        bindSlotLocked(slot);
+    }
+    void renderTaskAsyncInto(size_t slot, RenderTask &task, pt_stream stream)
+    {
+        std::lock_guard<std::mutex> lk(bindMu_);
+        bindSlotLocked(slot);
+        renderTaskAsync(task, stream);
+    }
+    void gatherTaskFrom(size_t slot, const RenderTask &task, pt_stream stream)
+    {
+        std::lock_guard<std::mutex> lk(bindMu_);
+        bindSlotLocked(slot);
+        gatherTask(task, stream);
+    }
+
     // camera parameters are read from the borrowed CameraConfig at every launch (by value, :210)
     void reloadCamera() {}
 
@@ -90,6 +129,9 @@ public:
         Resolution r = framebuffer_->getResolution();
         checkPtErrors(pt_fb_alloc(dev_, (int)r.width, (int)r.height, &d_rgb_, &d_yuv_));
         checkPtErrors(pt_bind_framebuffer(dev_, (int)r.width, (int)r.height, d_rgb_, d_yuv_));
+        const unsigned frames = ring_.size() > 1 ? (unsigned)ring_.size() - 1 : 1;
+        if (ring_.empty()) ring_.assign(1, {d_rgb_, d_yuv_});
+        else { ring_[0] = {d_rgb_, d_yuv_}; setFramesInFlight(frames); }      // the ring follows the resolution
     }
 
     void setSamplesPerPixel(unsigned int samplesPerPixel) { samplesPerPixel_ = samplesPerPixel; }
@@ -128,12 +170,19 @@ public:
     ~DevicePathTracer()
     {
         if (dev_) {
+            for (size_t i = 1; i < ring_.size(); i++) pt_fb_free(dev_, ring_[i].first, ring_[i].second);
             if (d_rgb_) pt_fb_free(dev_, d_rgb_, d_yuv_);
             pt_device_destroy(dev_);
         }
     }
 
 private:
+    void bindSlotLocked(size_t slot)
+    {
+        const auto &b = ring_[slot % ring_.size()];
+        Resolution r = framebuffer_->getResolution();
+        checkPtErrors(pt_bind_framebuffer(dev_, (int)r.width, (int)r.height, b.first, b.second));
+    }
     pt_camera cameraByValue() const
     {
         const CameraConfig &c = cameraConfig_;
@@ -143,6 +192,8 @@ private:
     int device_idx_;
     pt_device *dev_ = nullptr;
     uint8_t *d_rgb_ = nullptr, *d_yuv_ = nullptr;
+    std::vector<std::pair<uint8_t *, uint8_t *>> ring_{};     // device framebuffers: [0] = (d_rgb_, d_yuv_), + framesInFlight more when > 1
+    std::mutex bindMu_{};
     Dim3 threadBlockSize_;
     HostScene &hostScene_;
     unsigned int samplesPerPixel_;

@@ -76,10 +76,15 @@ public:
         bisectionDepth_ = (int)std::log2((double)threadCount_);
         bandQueue_.build((int)config_.resolution.width, (int)config_.resolution.height);
         queueActive_.store(config_.algorithmType == DQRB);
-        for (unsigned i = 0; i < config_.gpuNumber; i++)
+        // frames in flight: FSFL only (the adaptive policies time a task that has the device to itself)
+        fif_ = config_.algorithmType == FSFL ? std::max(1u, config_.framesInFlight) : 1u;
+        frameIndex_.store(0); firstValid_.store(0); draining_.store(false); inflight_ = 0;
+        for (unsigned i = 0; i < config_.gpuNumber; i++) {
             devicePathTracers_.push_back(std::make_shared<DevicePathTracer>(
                 (int)i, config_.samplesPerPixel, config_.recursionDepth, config_.threadBlockSize, hScene_, framebuffer_,
                 cameraConfig_));
+            if (fif_ > 1) devicePathTracers_.back()->setFramesInFlight(fif_);
+        }
         // The gather group is made BEFORE any worker thread exists: nothing is parked on the barrier if it fails.  It
         // only fails on a HIP error: without a usable librccl (or when ncclCommInitAll refuses) the group moves the same
         // strings with peer copies (pt_gather_transport says which).  If even that cannot be set up, every worker copies
@@ -104,17 +109,22 @@ public:
             streamThreads_.emplace_back();
             for (unsigned j = 0; j < config_.streamsPerGpu; j++) {
                 int taskIdx = (int)(i * config_.streamsPerGpu + j);
+                StreamThread::Pipeline pipe;
+                if (fif_ > 1) { pipe.frames = fif_; pipe.frameIndex = &frameIndex_; pipe.firstValid = &firstValid_; pipe.draining = &draining_; }
                 streamThreads_[i].push_back(std::make_shared<StreamThread>((int)i, taskIdx, devicePathTracers_[i], renderTasks_, barrier_,
-                                                                          gatherOnWorker, &bandQueue_, &queueActive_));
+                                                                          gatherOnWorker, &bandQueue_, &queueActive_, pipe));
                 streamThreads_[i][j]->start();
             }
         }
     }
 
     // The frame's one exchange step with several GPUs: task k was rendered by GPU k / streamsPerGpu (setup()).
-    void gatherFrame()
+    void gatherFrame(long slot = -1)
     {
         if (!gather_) return;
+        // frames in flight: the exchange moves the COMPLETED frame, which sits in its own slot of every engine's ring (the
+        // workers are parked between frames, nobody else binds meanwhile)
+        if (slot >= 0) for (auto &dpt : devicePathTracers_) dpt->bindSlot((size_t)slot);
         std::vector<pt_task> tasks;
         std::vector<int> owner;
         if (queueActive_.load()) {                         // DQRB: band b was rendered by whoever pulled it this frame
@@ -154,10 +164,22 @@ public:
     void setSchedulingAlgorithm(SchedulingAlgorithmType alg) { newConfig_.algorithmType = alg; dirty_ = true; }
     void setShowTasks(bool val) { newConfig_.showTasks = val; dirty_ = true; }
 
+    void setFramesInFlight(unsigned frames) { newConfig_.framesInFlight = std::max(1u, frames); dirty_ = true; }
+
     void updatePathTracingParamsIfNeeded()
     {
         if (!dirty_) return;
         dirty_ = false;
+        flush();                                       // parameters change between frames: nothing stays in flight across them
+        const unsigned wantFif = newConfig_.algorithmType == FSFL ? std::max(1u, newConfig_.framesInFlight) : 1u;
+        if (wantFif != fif_) {                         // the workers' streams and the engines' rings follow the pipeline depth
+            reset();
+            config_ = newConfig_;
+            framebuffer_->setResolution(config_.resolution);
+            setup();
+            return;
+        }
+        config_.framesInFlight = newConfig_.framesInFlight;
         config_.algorithmType = newConfig_.algorithmType;
         config_.showTasks = newConfig_.showTasks;
         config_.kParam = newConfig_.kParam;
@@ -291,6 +313,7 @@ public:
         if (config_.algorithmType == DSFL) adjustTasksDSFL();
         else if (config_.algorithmType == DSDL) adjustTasksDSDL();
         else if (config_.algorithmType == DQRB) bandQueue_.beginFrame();
+        if (fif_ > 1) { pipelineRound(false); return; }
         barrier_.wait();     // release the workers
         barrier_.wait();     // all tasks rendered (and, with one GPU, gathered by their workers)
         if (config_.algorithmType == DQRB && !bandQueue_.everyBandExactlyOnce())
@@ -298,6 +321,16 @@ public:
         gatherFrame();       // several GPUs: one RCCL exchange to GPU 0 + one copy to the host
         if (config_.showTasks) markTasks();
     }
+
+    // Frames in flight: complete every launched frame, oldest first; afterwards the Framebuffer holds the last frame launched.
+    void flush()
+    {
+        while (fif_ > 1 && inflight_ > 0) pipelineRound(true);
+        if (fif_ > 1) firstValid_.store(frameIndex_.load());
+    }
+    unsigned framesInFlight() const { return fif_; }
+    // true when the Framebuffer holds a frame completed by the latest renderFrame() / flush()
+    bool frameCompleted() const { return completedLast_; }
 
     // per-task milliseconds and imbalance = max / mean (RenderManager.h:433-447)
     float imbalance() const
@@ -354,6 +387,25 @@ public:
     std::vector<std::shared_ptr<DevicePathTracer>> &tracers() { return devicePathTracers_; }
 
 private:
+    // One round of the frames-in-flight protocol: the workers launch frame i (unless draining) and complete frame
+    // i - F + 1 (StreamThread::threadMain); with several GPUs the completed frame is then exchanged out of its ring slot.
+    void pipelineRound(bool draining)
+    {
+        const long F = (long)fif_, i = frameIndex_.load(), j = i - (F - 1);
+        draining_.store(draining);
+        barrier_.wait();
+        barrier_.wait();
+        if (!draining) inflight_++;
+        completedLast_ = j >= 0 && j >= firstValid_.load();
+        if (completedLast_) {
+            inflight_--;
+            gatherFrame(j % (F + 1));
+            if (config_.showTasks) markTasks();
+        }
+        draining_.store(false);
+        frameIndex_.store(i + 1);
+    }
+
     // Equal-time division points of a row of tasks (in pixels, multiples of `block`), assuming
     // each task's time is spread evenly over its blocks (RenderManager.h:546-603).
     static std::vector<int> equalTimeDividers(const std::vector<int> &times, const std::vector<int> &lens, int block, int total)
@@ -433,6 +485,13 @@ private:
     std::string gatherTransport_{};
     BandQueue bandQueue_{};
     std::atomic_bool queueActive_{false};
+    // frames in flight (RendererConfig::framesInFlight, FSFL only)
+    unsigned fif_ = 1;
+    std::atomic<long> frameIndex_{0};       // the round the workers run next
+    std::atomic<long> firstValid_{0};       // rounds before it were flushed: nothing of theirs is left to complete
+    std::atomic_bool draining_{false};
+    long inflight_ = 0;                     // frames launched and not yet completed
+    bool completedLast_ = true;
 };
 
 } // namespace ptamd

@@ -42,6 +42,10 @@ struct RendererConfig {
     unsigned int maxTasksInRow = 2;
     bool showTasks = true;
     int kParam = 1;
+    // Not in the reference (its renderFrame ends on a barrier, RenderManager.h:410-431): frames rendered concurrently per
+    // GPU, each in its own device framebuffer on its own stream.  With F > 1 renderFrame() launches frame i and hands out
+    // frame i - F + 1 (RenderManager::flush() completes the rest); FSFL only -- the adaptive policies time a task alone.
+    unsigned int framesInFlight = 1;
 };
 
 struct CameraConfig {

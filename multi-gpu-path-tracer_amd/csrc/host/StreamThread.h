@@ -18,18 +18,32 @@
 
 namespace ptamd {
 
+// Frames in flight (RendererConfig::framesInFlight > 1): `frames` of them per GPU, the round counter, the first round that
+// still holds a frame and the "only complete, launch nothing" flag of RenderManager::flush(), all owned by the
+// RenderManager (null pointers: one frame at a time).
+struct StreamPipeline {
+    unsigned frames = 1;
+    const std::atomic<long> *frameIndex = nullptr;
+    const std::atomic<long> *firstValid = nullptr;     // rounds before this one hold no frame to complete (everything was flushed)
+    const std::atomic_bool *draining = nullptr;
+};
+
 class StreamThread {
 public:
     // gatherOnWorker: this worker copies its finished rectangle to the host itself (single GPU); otherwise the
     // RenderManager gathers all devices' rectangles in one RCCL exchange after the frame barrier.
     // queue: the DQRB policy's band queue (nullptr or inactive = the reference's one pre-assigned task per frame).
+    typedef StreamPipeline Pipeline;
+
     StreamThread(int device_idx, int task_idx, std::shared_ptr<DevicePathTracer> devicePathTracer,
                  std::vector<RenderTask> &tasks, Barrier &barrier, bool gatherOnWorker = true, BandQueue *queue = nullptr,
-                 const std::atomic_bool *queueActive = nullptr)
+                 const std::atomic_bool *queueActive = nullptr, Pipeline pipeline = Pipeline())
         : deviceIdx{device_idx}, taskIdx{task_idx}, devicePathTracer{devicePathTracer}, tasks_{tasks}, barrier_{barrier},
-          gatherOnWorker_{gatherOnWorker}, queue_{queue}, queueActive_{queueActive}
+          gatherOnWorker_{gatherOnWorker}, queue_{queue}, queueActive_{queueActive}, pipeline_{pipeline}
     {
         stream = devicePathTracer->createStream();
+        for (unsigned k = 1; k < pipeline_.frames; k++) moreStreams_.push_back(devicePathTracer->createStream());
+        launchedAt_.resize(pipeline_.frames);
     }
 
     ~StreamThread()
@@ -37,6 +51,7 @@ public:
         shouldTerminate = true;
         if (thread_.joinable()) thread_.join();
         devicePathTracer->destroyStream(stream);
+        for (pt_stream s : moreStreams_) devicePathTracer->destroyStream(s);
     }
 
     void start() { thread_ = std::thread(&StreamThread::threadMain, this); }
@@ -48,7 +63,24 @@ public:
         while (true) {
             barrier_.wait();                       // frame start (RenderManager::renderFrame)
             if (shouldTerminate) return;
-            if (queue_ && queueActive_ && queueActive_->load()) {
+            if (pipeline_.frames > 1 && pipeline_.frameIndex && (size_t)taskIdx < tasks_.size()) {
+                // Frames in flight: launch frame i into ring slot i % (F + 1) on stream i % F, then complete frame i - F + 1
+                // (wait for its stream, copy its rectangle out of ITS slot).  While flushing nothing is launched.
+                const long F = (long)pipeline_.frames, i = pipeline_.frameIndex->load();
+                const bool draining = pipeline_.draining && pipeline_.draining->load();
+                RenderTask &task = tasks_[(size_t)taskIdx];
+                if (!draining) {
+                    launchedAt_[(size_t)(i % F)] = std::chrono::high_resolution_clock::now();
+                    devicePathTracer->renderTaskAsyncInto((size_t)(i % (F + 1)), task, streamOf(i % F));
+                }
+                const long j = i - (F - 1);
+                if (j >= 0 && (!pipeline_.firstValid || j >= pipeline_.firstValid->load())) {
+                    devicePathTracer->synchronizeStream(streamOf(j % F));
+                    auto stop = std::chrono::high_resolution_clock::now();
+                    task.time = (int)std::chrono::duration_cast<std::chrono::milliseconds>(stop - launchedAt_[(size_t)(j % F)]).count();
+                    if (gatherOnWorker_) devicePathTracer->gatherTaskFrom((size_t)(j % (F + 1)), task, streamOf(j % F));
+                }
+            } else if (queue_ && queueActive_ && queueActive_->load()) {
                 // DQRB: pull bands until the frame's queue is empty; this worker's stream never idles while work is left
                 for (int b = queue_->pull(deviceIdx); b >= 0; b = queue_->pull(deviceIdx)) {
                     RenderTask &band = queue_->bands[(size_t)b];
@@ -76,6 +108,8 @@ public:
     }
 
 private:
+    pt_stream streamOf(long k) const { return k == 0 ? stream : moreStreams_[(size_t)k - 1]; }
+
     int deviceIdx;
     int taskIdx;
     std::atomic_bool shouldTerminate{false};
@@ -87,6 +121,9 @@ private:
     bool gatherOnWorker_ = true;
     BandQueue *queue_ = nullptr;
     const std::atomic_bool *queueActive_ = nullptr;
+    Pipeline pipeline_{};
+    std::vector<pt_stream> moreStreams_{};                                        // streams 1 .. F - 1 of the pipeline
+    std::vector<std::chrono::high_resolution_clock::time_point> launchedAt_{};    // when the frame on stream k was launched
 };
 
 } // namespace ptamd

@@ -1,6 +1,7 @@
 // main.cpp -- `pt_render`: the .glb -> PPM driver on top of RenderManager, replacing the
 // reference's main.cu:33-95 (whose only sinks are a websocket stream or a GL window).
 //   pt_render <jobId> <model.glb|.obj> [options]      (argv[1], argv[2] as ArgumentLoader.h:10-13)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +36,7 @@ int main(int argc, char **argv)
         else if (a == "--streams") config.streamsPerGpu = (unsigned)atoi(next());
         else if (a == "--max-tasks-in-row") config.maxTasksInRow = (unsigned)atoi(next());
         else if (a == "--frames") frames = atoi(next());
+        else if (a == "--frames-in-flight") config.framesInFlight = (unsigned)std::max(1, atoi(next()));
         else if (a == "--out") out = next();
         else if (a == "--yuv") yuvOut = next();
         else if (a == "--cornell") cornell = true;
@@ -67,6 +69,22 @@ int main(int argc, char **argv)
     std::cout << "initializing in: " << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << "ms" << std::endl;
 
     if (sah) for (auto &dpt : manager.tracers()) dpt->setBvhMode(1);
+    if (manager.framesInFlight() > 1) {
+        // Frames in flight: renderFrame() launches frame f and hands out frame f - F + 1; the counters of overlapping frames
+        // cannot be told apart, so the run is reported as a whole (pipeline empty at both ends).
+        for (auto &dpt : manager.tracers()) dpt->resetCounters();
+        auto start = std::chrono::high_resolution_clock::now();
+        for (int f = 0; f < frames; f++) manager.renderFrame();
+        manager.flush();
+        auto stop = std::chrono::high_resolution_clock::now();
+        double ms = std::chrono::duration<double, std::milli>(stop - start).count();
+        std::cout << "Path Tracing took: " << (long)ms << "ms" << std::endl;
+        unsigned long long seg = 0;
+        for (auto &dpt : manager.tracers()) seg += dpt->readCounters().segments;
+        printf("{\"frames\": %d, \"frames_in_flight\": %u, \"ms\": %.3f, \"ms_per_frame\": %.3f, \"segments\": %llu, \"segments_per_s\": %.4g, \"tasks\": %zu}\n",
+               frames, manager.framesInFlight(), ms, ms / std::max(frames, 1), seg, (double)seg / (ms * 1e-3), manager.tasks().size());
+        frames = 0;
+    }
     for (int f = 0; f < frames; f++) {
         for (auto &dpt : manager.tracers()) dpt->resetCounters();
         auto start = std::chrono::high_resolution_clock::now();

@@ -368,6 +368,27 @@ def test_cpp_driver_glb_to_ppm_matches_oracle(pt, box_oracle, gpu_device, tmp_pa
         assert all(f["tasks"] == 8 for f in frames)                                      # 64 rows in bands of 8
 
 
+@pytest.mark.parametrize("extra", [["--frames-in-flight", "2"], ["--frames-in-flight", "3", "--streams", "2"],
+                                   ["--frames-in-flight", "2", "--streams", "4", "--max-tasks-in-row", "2"]])
+def test_cpp_driver_frames_in_flight(pt, box_oracle, gpu_device, tmp_path, extra):
+    """The C++ host with RendererConfig::framesInFlight > 1 (`pt_render --frames-in-flight F`): every worker launches frame i
+    into slot i % (F + 1) of its engine's ring of device framebuffers on stream i % F and copies frame i - F + 1 out of ITS
+    slot; RenderManager::flush() completes the rest.  Seven frames: the last one handed out is the oracle's, and the
+    engines' segment counters add up to seven frames' worth -- every frame was rendered whole, none twice."""
+    exe = os.path.join(ROOT, "multi-gpu-path-tracer_amd", "pt_render")
+    out, yuv = tmp_path / "o.ppm", tmp_path / "o.yuv"
+    cmd = [exe, "0", os.path.join(ROOT, "models", "cornell_box.glb"), "--cornell", "--width", "96", "--height", "64",
+           "--spp", "4", "--depth", "4", "--frames", "7", "--out", str(out), "--yuv", str(yuv)] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    ref = box_oracle.render(BOX_CAMERA, 96, 64, 4, 4, threads=8)
+    assert np.array_equal(_read_ppm(str(out)), ref[0])
+    assert np.array_equal(np.frombuffer(yuv.read_bytes(), np.uint8), ref[1])
+    import json
+    line = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    assert line["frames"] == 7 and line["frames_in_flight"] == int(extra[1]) and line["segments"] == 7 * ref[2]["segments"]
+
+
 def test_cpp_driver_dsdl_on_a_frame_too_thin_to_bisect(pt, box_oracle, gpu_device, tmp_path):
     """a 16x8 frame is a 2x1 block grid; eight workers ask for three levels of bisection and two of them
     cannot cut.  The degenerate branch must still yield 2^(depth - level) tasks (most of them empty), so that DSDL's new
