@@ -259,13 +259,20 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on a box with ONE GPU: every rank uses cuda:0 and the exchange runs "
                          "over gloo (RCCL needs one GPU per rank); checks the N > 1 code path, not its speed")
-    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
                     help="frames rendered concurrently, each in its own framebuffer on its own stream: the next frame's waves "
-                         "take the wave slots the current frame's last chains leave idle.  0 = the default (2 for N > 1, 1 on one GPU)")
+                         "take the wave slots the current frame's last chains leave idle.  0 = the default (2; 4 from eight ranks on; "
+                         "1 with the cost-fed dealers)")
     ap.add_argument("--share-of", type=int, default=0,
                     help="diagnostic (1 GPU): time only rank 0's row bands of an N-rank split, print a "
                          "diagnostic line instead of the metric line")
     args = ap.parse_args()
+
+    # More than three launches only overlap on the device when each has a hardware queue of its own: the HIP runtime maps
+    # streams onto 4 queues by default, and a launch behind another stream's persistent kernel on a shared queue waits for
+    # it (an eighth of C2 with 4 frames in flight: 9.9 ms per frame on 4 queues, 7.8 on 8).  Read when the runtime
+    # initialises: set before torch is imported, and handed on to the ranks this process may start.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Started without a launcher (`python bench.py --gpus N`): this process becomes the launcher.  It has not
@@ -327,12 +334,12 @@ def main():
     bvh = args.bvh or ("sah" if args.config == "c4" else "reference")
     desc += " [bvh=%s]" % bvh
     t_up = time.perf_counter()
-    # Frames in flight (scheduling.py RenderManager): every GPU keeps two frames queued (three from eight ranks on, where a
+    # Frames in flight (scheduling.py RenderManager): every GPU keeps two frames queued (four from eight ranks on, where a
     # share is an eighth of a frame and its dearest chains leave the device idle for half of its time), each in its own
     # framebuffer on its own stream: the next frame's waves take the wave slots the current frame's last chains leave empty
-    # (one GPU, C2: 59.6 -> 55.9 ms per frame; an eighth of C2: 13.7 -> 8.8 ms; profiles/r03_frames_in_flight.json).  The
+    # (one GPU, C2: 59.6 -> 55.6 ms per frame; an eighth of C2: 13.7 -> 7.8 ms; profiles/r03_frames_in_flight.json).  The
     # timed region starts and ends with an empty pipeline.  The cost-fed dealers keep one frame in flight.
-    fif = args.frames_in_flight or ((3 if world >= 8 else 2) if (world == 1 or algo == "fsfl") else 1)
+    fif = args.frames_in_flight or ((4 if world >= 8 else 2) if (world == 1 or algo == "fsfl") else 1)
     mgr = pt.RenderManager(cfg, scene, cam, device_idx=local_rank, band_rows=args.band_rows,
                            bvh_mode=1 if bvh == "sah" else 0, frames_in_flight=fif)
     fif = mgr.frames_in_flight

@@ -17,6 +17,9 @@ static bool parse3(const char *s, Float3 &out) { return sscanf(s, "%f,%f,%f", &o
 
 int main(int argc, char **argv)
 {
+    // more than three frames in flight only overlap when each launch has a hardware queue of its own (the HIP runtime's
+    // default is 4 queues for all streams of the process); read when the runtime initialises, i.e. before the first engine
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     RendererConfig config;
     config.jobId = (argc > 1 && argv[1][0] != '\0') ? argv[1] : "0";
     config.modelPath = (argc > 2 && argv[2][0] != '\0') ? argv[2] : "models/cornell_duck.glb";

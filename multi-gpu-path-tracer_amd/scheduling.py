@@ -338,6 +338,8 @@ class RenderManager:
         # flight; profiles/r03_frames_in_flight.json).  F + 1 framebuffers form a ring, so the last COMPLETE frame
         # (getFramebuffer / getCurrentFrame) stays untouched until the next renderFrame().  Images are the same frames in the
         # same order.  The cost-fed dealers (DSFL / DSDL) re-deal between consecutive frames and keep one frame in flight.
+        # More than three launches only overlap when each has a hardware queue of its own: the HIP runtime maps the streams
+        # of a process onto 4 queues unless GPU_MAX_HW_QUEUES says otherwise BEFORE the runtime initialises (bench.py sets 8).
         self.frames_in_flight = max(1, int(frames_in_flight))
         if self.dynamic():
             self.frames_in_flight = 1
