@@ -232,8 +232,8 @@ ROOFLINE_NOTES["c1"] = ROOFLINE_NOTES["c5"] = ROOFLINE_NOTES["c2"]
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)      # (frames in flight: the pipeline is empty at both ends of the timed
+    ap.add_argument("--warmup", type=int, default=3)      #  region, so a handful of frames would mostly measure its filling)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--algo", default=None, choices=["fsfl", "dsfl"],
