@@ -261,8 +261,8 @@ def main():
                          "over gloo (RCCL needs one GPU per rank); checks the N > 1 code path, not its speed")
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=[0, 1, 2, 3, 4, 5, 6],
                     help="frames rendered concurrently, each in its own framebuffer on its own stream: the next frame's waves "
-                         "take the wave slots the current frame's last chains leave idle.  0 = the default (2; 4 from eight ranks on; "
-                         "1 with the cost-fed dealers)")
+                         "take the wave slots the current frame's last chains leave idle.  0 = the default (2 on one GPU, 3 from two ranks "
+                         "on, 4 from eight; 1 with the cost-fed dealers)")
     ap.add_argument("--share-of", type=int, default=0,
                     help="diagnostic (1 GPU): time only rank 0's row bands of an N-rank split, print a "
                          "diagnostic line instead of the metric line")
@@ -334,12 +334,13 @@ def main():
     bvh = args.bvh or ("sah" if args.config == "c4" else "reference")
     desc += " [bvh=%s]" % bvh
     t_up = time.perf_counter()
-    # Frames in flight (scheduling.py RenderManager): every GPU keeps two frames queued (four from eight ranks on, where a
-    # share is an eighth of a frame and its dearest chains leave the device idle for half of its time), each in its own
+    # Frames in flight (scheduling.py RenderManager): one GPU keeps two frames queued, the ranks of a multi-GPU run three
+    # (four from eight ranks on, where a share is an eighth of a frame and its dearest chains leave the device idle for half
+    # of its time; the third changes nothing for the box but much for the latency-bound SAH kernels), each in its own
     # framebuffer on its own stream: the next frame's waves take the wave slots the current frame's last chains leave empty
     # (one GPU, C2: 59.6 -> 55.6 ms per frame; an eighth of C2: 13.7 -> 7.8 ms; profiles/r03_frames_in_flight.json).  The
     # timed region starts and ends with an empty pipeline.  The cost-fed dealers keep one frame in flight.
-    fif = args.frames_in_flight or ((4 if world >= 8 else 2) if (world == 1 or algo == "fsfl") else 1)
+    fif = args.frames_in_flight or ((4 if world >= 8 else 3 if world > 1 else 2) if (world == 1 or algo == "fsfl") else 1)
     mgr = pt.RenderManager(cfg, scene, cam, device_idx=local_rank, band_rows=args.band_rows,
                            bvh_mode=1 if bvh == "sah" else 0, frames_in_flight=fif)
     fif = mgr.frames_in_flight
