@@ -1761,6 +1761,20 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
             P.stack_spill = ev.spill;
         }
     }
+    // Frames in flight: launches of this device that are still running when this one is enqueued share its wave slots with
+    // it (the pending launches' end events, newest first; launches finish roughly in the order they were enqueued).
+    unsigned sharing = 1;
+    {
+        std::lock_guard<std::mutex> lk(dev->mu);
+        for (auto it = dev->pending.rbegin(); it != dev->pending.rend() && sharing < 8u; ++it) {
+            if (hipEventQuery(it->second) == hipSuccess) break;
+            sharing++;
+        }
+        (void)hipGetLastError();      // hipEventQuery reports "not ready" through the error state
+    }
+    // Issue priority by remaining samples keeps a lone launch's last waves from starving; when another launch's waves fill
+    // the slots anyway it only costs (C2, two frames in flight: 55.7 ms per frame with it, 55.0 without).
+    if (sharing > 1) P.lrpt = 0;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(dev::kBlock), lds, hs, P);
     PT_HIP_LAUNCH(hipGetLastError());
     PT_HIP_LAUNCH(hipEventRecord(ev.second, hs));
@@ -1772,19 +1786,10 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
             const unsigned resident = (unsigned)(dev->cu_count * resident_per_cu(dev, (const void *)kern, lds)) * dev::kWavesPerBlock;
             // extra waves the split may add: the wave slots this launch leaves empty, or an eighth of all of them
             const unsigned spare = std::max(resident / 8u, resident > sched->slots ? resident - sched->slots : 0u);
-            // Frames in flight: launches of this device that are still running when this one is enqueued share its wave slots
-            // with it.  Splitting buys a shorter chain with 2.6 x a tile's work, which only pays while slots would idle
-            // otherwise: the "evenly spread launch" the dearest tile is compared with spreads over this launch's SHARE of the
-            // slots (a quarter of C2, two frames in flight: 15.9 ms per frame split, 14.9 unsplit; profiles/r03_frames_in_flight.json).
-            unsigned sharing = 1;
-            {
-                std::lock_guard<std::mutex> lk(dev->mu);
-                for (auto it = dev->pending.rbegin(); it != dev->pending.rend() && sharing < 8u; ++it) {
-                    if (hipEventQuery(it->second) == hipSuccess) break;     // launches finish roughly in the order they were enqueued
-                    sharing++;
-                }
-                (void)hipGetLastError();      // hipEventQuery reports "not ready" through the error state
-            }
+            // Launches that share the device (`sharing`, above): splitting buys a shorter chain with 2.6 x a tile's work, which
+            // only pays while slots would idle otherwise: the "evenly spread launch" the dearest tile is compared with spreads
+            // over this launch's SHARE of the slots (a quarter of C2, two frames in flight: 15.9 ms per frame split, 14.9
+            // unsplit; profiles/r03_frames_in_flight.json).
             hipLaunchKernelGGL(dev::split_count_kernel, dim3(1), dim3(256), 0, hs, sched->sorted_cost, sched->slots, std::max(1u, resident / sharing), std::max(1u, spare / (unsigned)(split_parts - 1)), (unsigned)(dev->split_pct > 0 ? dev->split_pct : walk == 4 ? 110 : 90),
                                (unsigned)(dev->split_ratio > 0 ? dev->split_ratio : walk == 4 ? 65 : 80), sched->n_split);
             PT_HIP_LAUNCH(hipGetLastError());
