@@ -260,7 +260,7 @@ def _in_flight_worker(rank, world, port, W, H, band, fif, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,fif", [(2, 2), (3, 3)])
+@pytest.mark.parametrize("world,fif", [(2, 2), (3, 3), (8, 4)])      # (8, 4): what bench.py runs on a whole node
 def test_frames_in_flight_exchange_one_batch_per_completed_frame_in_order(tmp_path, world, fif):
     mp.spawn(_in_flight_worker, args=(world, _free_port(), 64, 72, 8, fif, str(tmp_path)), nprocs=world, join=True)
     calls = [eval((tmp_path / ("calls_%d.txt" % r)).read_text()) for r in range(world)]
