@@ -246,7 +246,7 @@ def _rank_worker_in_flight(rank, world, port, W, H, spp, depth, band, out_path, 
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,fif,W,H,band", [(2, 2, 96, 64, 8), (3, 3, 64, 40, 8), (1, 2, 96, 64, 8)])
+@pytest.mark.parametrize("world,fif,W,H,band", [(2, 2, 96, 64, 8), (3, 3, 64, 40, 8), (1, 2, 96, 64, 8), (4, 4, 64, 64, 8)])
 def test_frames_in_flight_render_the_same_frames(box_oracle, gpu_device, tmp_path, world, fif, W, H, band):
     """RenderManager(frames_in_flight = F): renderFrame() launches frame i and completes frame i - F + 1, F launches queued
     per GPU, each in its own buffer of a ring of F + 1 on its own stream, the exchange per frame in launch order.  Every
