@@ -101,6 +101,11 @@ public:
                 if (gatherOnWorker_) devicePathTracer->gatherTask(task, stream);
             }
             barrier_.wait();                       // frame end
+#ifdef PTAMD_TEST_AFTER_FRAME_END
+            // test seam (tests/native/stream_thread_teardown_check.cpp): a statement run by the worker right after the frame-end
+            // barrier, where the teardown race lived; never defined in a product build
+            PTAMD_TEST_AFTER_FRAME_END
+#endif
             // (No termination check here: RenderManager::reset() raises the flag and then joins the frame-START barrier with
             // every worker.  A worker that left after the frame-end barrier -- the flag can already be up when it wakes, if
             // the frame was short -- would never arrive there, and the ones that did would wait for it forever.)

@@ -333,7 +333,8 @@ static inline int sah_bin(float scaled, int bins)
 struct SahBuilder {
     std::vector<SahTri> &tris;
     std::vector<SahNode> nodes;     // per-subtree pools are merged by the caller
-    explicit SahBuilder(std::vector<SahTri> &t) : tris(t) {}
+    uint32_t max_leaf;              // ranges of at most this many triangles become leaves
+    explicit SahBuilder(std::vector<SahTri> &t, uint32_t leaf = 4) : tris(t), max_leaf(leaf) {}
 
     static void grow(float *mn, float *mx, const float *a, const float *b)
     {
@@ -354,7 +355,7 @@ struct SahBuilder {
         for (uint32_t i = lo; i < hi; i++) { grow(mn, mx, tris[i].bmin, tris[i].bmax); grow(cmn, cmx, tris[i].c, tris[i].c); }
         for (int k = 0; k < 3; k++) { nodes[id].bmin[k] = mn[k]; nodes[id].bmax[k] = mx[k]; }
         uint32_t n = hi - lo;
-        if (n <= 4 || depth >= 60) { nodes[id].first = lo; nodes[id].count = n; return id; }
+        if (n <= max_leaf || depth >= 60) { nodes[id].first = lo; nodes[id].count = n; return id; }
         constexpr int kBins = 16;
         float best = FLT_MAX;
         int best_axis = -1, best_bin = 0;
@@ -407,7 +408,7 @@ struct SahBuilder {
             // big subtrees: the left half on another host thread with its own node pool (the two
             // halves touch disjoint ranges of `tris`), merged behind this pool afterwards.  The
             // resulting tree does not depend on the thread schedule.
-            SahBuilder other(tris);
+            SahBuilder other(tris, max_leaf);
             auto fut = std::async(std::launch::async, [&other, lo, mid, depth] { return other.build(lo, mid, depth + 1); });
             r = build(mid, hi, depth + 1);
             int lroot = fut.get();
@@ -429,7 +430,7 @@ struct SahBuilder {
 
 } // namespace
 
-void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out)
+void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out, uint32_t max_leaf)
 {
     out = SahBvh();
     std::vector<SahTri> tris(n_tris);
@@ -445,7 +446,7 @@ void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out)
         }
         t.face = (int)i;
     }
-    SahBuilder b(tris);
+    SahBuilder b(tris, max_leaf < 1 ? 1u : max_leaf);
     b.nodes.reserve(n_tris);
     int root = b.build(0, (uint32_t)n_tris, 0);
     // epsilon: absolute part from the scene extent, relative part from the coordinate magnitude

@@ -99,7 +99,8 @@ struct SahBvh {
     std::vector<int> order;
     uint32_t max_stack = 0, max_leaf = 0;
 };
-void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out);
+// max_leaf: ranges of at most this many triangles become leaves (the device forms take up to 15 per leaf).
+void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out, uint32_t max_leaf = 4);
 
 // The SAH tree in 4-wide form for the device (pt_walk.h, wide SAH walk): a QuadNode holds up to four child boxes, made
 // from a pair by replacing its larger inner children with their own two children.  128 B = two NodePair-sized halves:

@@ -77,6 +77,8 @@ def lib():
         L.ptor_kat_tri_hit.argtypes = [vp, vp, vp, C.c_float, C.c_float, vp]
         L.ptor_kat_closest_hit.restype = C.c_int
         L.ptor_kat_closest_hit.argtypes = [vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        L.ptor_kat_brute_closest.restype = C.c_int
+        L.ptor_kat_brute_closest.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -211,3 +213,24 @@ def tri_hit(v9, o, d, tmin=0.001, tmax=3.402823466e+38):
     out = np.zeros(3, np.float32)
     h = lib().ptor_kat_tri_hit(v.ctypes.data, o.ctypes.data, d.ctypes.data, tmin, tmax, out.ctypes.data)
     return h, out
+
+
+def brute_closest(triangles, origins, dirs, threads=8):
+    """Closest accepted hit of every ray by brute force over ALL triangles in face order (no tree): (t, face, ties) per
+    ray; t = -1 / face = -1 for a miss, ties = faces sharing the smallest t."""
+    from concurrent.futures import ThreadPoolExecutor
+    tris = np.ascontiguousarray(triangles)
+    o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+    n = len(o)
+    t = np.zeros(n, np.float32); f = np.zeros(n, np.int32); ties = np.zeros(n, np.int32)
+    L = lib()
+
+    def run(k):
+        a, b = n * k // threads, n * (k + 1) // threads
+        if b > a:
+            L.ptor_kat_brute_closest(tris.ctypes.data, len(tris), o[a:b].ctypes.data, d[a:b].ctypes.data, b - a,
+                                     t[a:b].ctypes.data, f[a:b].ctypes.data, ties[a:b].ctypes.data)
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(run, range(threads)))
+    return t, f, ties

@@ -920,3 +920,59 @@ int ptor_kat_closest_hit(const ptor_scene *sc, const float o[3], const float d[3
     *t_out = rec.t; *mat_out = rec.mat;
     return err ? -1 : h;
 }
+
+/* Brute force over ALL triangles, in face order, without any tree (tests only): per ray the smallest t that
+ * triangle.h:63-113 accepts in (tmin, FLT_MAX), the first face that reaches it and how many faces share that t.
+ * What any correct traversal's closest hit must equal, whatever boxes it walked through.  The test is tri_hit's
+ * arithmetic (same expressions, same order), without the record fill; triangles outside, rays inside, so that a
+ * triangle's edges are formed once per block of rays.                                                           */
+typedef float ptor_vf __attribute__((vector_size(32)));
+typedef int ptor_vi __attribute__((vector_size(32)));
+__attribute__((target_clones("avx2", "default")))
+int ptor_kat_brute_closest(const ptor_triangle *tris, int ntris, const float *o3, const float *d3, int n_rays,
+                           float *t_out, int *face_out, int *ties_out)
+{
+    for (int i = 0; i < n_rays; i++) { t_out[i] = -1.0f; face_out[i] = -1; ties_out[i] = 0; }
+    enum { BLOCK = 64, LANES = 8, VEC = BLOCK / LANES };
+    /* Eight rays per operation (GCC vector types: every operation below is one IEEE binary32 operation per ray, as in
+     * tri_hit; 1.0f / det == (float)(1.0 / (double)det); the double compares of :78 are |det| <= 1e-8f). */
+    ptor_vf ox[VEC], oy[VEC], oz[VEC], dx[VEC], dy[VEC], dz[VEC];
+    ptor_vf zero, one, eps, tmin, big, minus1;
+    for (int l = 0; l < LANES; l++) { zero[l] = 0.0f; one[l] = 1.0f; eps[l] = 1e-8f; tmin[l] = 0.001f; big[l] = FLT_MAX; minus1[l] = -1.0f; }
+    for (int i0 = 0; i0 < n_rays; i0 += BLOCK) {
+        const int nb = n_rays - i0 < BLOCK ? n_rays - i0 : BLOCK;
+        for (int j = 0; j < BLOCK; j++) {
+            const int i = i0 + (j < nb ? j : 0);
+            ox[j / LANES][j % LANES] = o3[3 * i]; oy[j / LANES][j % LANES] = o3[3 * i + 1]; oz[j / LANES][j % LANES] = o3[3 * i + 2];
+            dx[j / LANES][j % LANES] = d3[3 * i]; dy[j / LANES][j % LANES] = d3[3 * i + 1]; dz[j / LANES][j % LANES] = d3[3 * i + 2];
+        }
+        for (int k = 0; k < ntris; k++) {
+            const ptor_triangle *h = &tris[k];
+            const float v0x = h->v0.px, v0y = h->v0.py, v0z = h->v0.pz;
+            const float e1x = h->v1.px - v0x, e1y = h->v1.py - v0y, e1z = h->v1.pz - v0z;
+            const float e2x = h->v2.px - v0x, e2y = h->v2.py - v0y, e2z = h->v2.pz - v0z;
+            for (int q = 0; q < VEC; q++) {
+                const ptor_vf px = dy[q] * e2z - dz[q] * e2y, py = dz[q] * e2x - dx[q] * e2z, pz = dx[q] * e2y - dy[q] * e2x;   /* cross3(d, e2) */
+                const ptor_vf det = e1x * px + e1y * py + e1z * pz;
+                const ptor_vf inv_det = one / det;
+                const ptor_vf tx = ox[q] - v0x, ty = oy[q] - v0y, tz = oz[q] - v0z;
+                const ptor_vf u = (tx * px + ty * py + tz * pz) * inv_det;
+                const ptor_vf qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;                     /* cross3(tvec, e1) */
+                const ptor_vf v = (dx[q] * qx + dy[q] * qy + dz[q] * qz) * inv_det;
+                const ptor_vf t = (e2x * qx + e2y * qy + e2z * qz) * inv_det;
+                const ptor_vi ok = ~((det <= eps) & (det >= -eps)) & ~((u < zero) | (u > one)) & ~((v < zero) | (u + v > one)) & ((t < big) & (t > tmin));
+                int any = 0;
+                for (int l = 0; l < LANES; l++) any |= ok[l];
+                if (any == 0) continue;
+                const ptor_vf tt = (ptor_vf)(((ptor_vi)t & ok) | ((ptor_vi)minus1 & ~ok));
+                for (int l = 0; l < LANES; l++) {
+                    const int j = LANES * q + l, i = i0 + j;
+                    if (!ok[l] || j >= nb) continue;
+                    if (face_out[i] < 0 || tt[l] < t_out[i]) { t_out[i] = tt[l]; face_out[i] = k; ties_out[i] = 1; }
+                    else if (tt[l] == t_out[i]) ties_out[i]++;
+                }
+            }
+        }
+    }
+    return 0;
+}

@@ -89,3 +89,78 @@ def test_c4_real_size_full_frame_properties(pt, c4_tracer):
     assert (h3, c3) == (h1, c1)
     img = fb.rgb_host()
     assert img[H // 2:].mean() > 10 and not img[:60].any()                   # lit terrain under a black sky
+
+
+def _gate_rays(terrain, n, seed=23):
+    """Rays for the closest-hit gate on the terrain, three kinds shuffled together: origins anywhere in the scene's bounds with
+    any direction (every 13th in a coordinate plane), camera rays of bench.py's C4 frustum, and bounce-like rays that leave
+    the terrain's surface into the upper half-space (the skimming rays whose walks are the long ones)."""
+    rng = np.random.default_rng(seed)
+    tris = terrain.triangles
+    pos = np.stack([tris[v]["position"] for v in ("v0", "v1", "v2")], axis=1).astype(np.float32)        # (n, 3, 3)
+    lo, hi = pos.reshape(-1, 3).min(axis=0), pos.reshape(-1, 3).max(axis=0)
+    n_vol, n_cam = (2 * n) // 5, n // 5
+    n_srf = n - n_vol - n_cam
+    o_vol = rng.uniform(lo, hi, (n_vol, 3)).astype(np.float32)
+    d_vol = rng.standard_normal((n_vol, 3), dtype=np.float32)
+    d_vol[::13, 2] = 0.0
+    o_cam = np.tile(np.asarray(TERRAIN_CAMERA[0], np.float32), (n_cam, 1))
+    sx, sy = rng.uniform(-0.4142, 0.4142, n_cam), rng.uniform(-0.4142, 0.4142, n_cam)
+    fwd = np.asarray(TERRAIN_CAMERA[1], np.float64); fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, [0.0, 1.0, 0.0]); right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    d_cam = (fwd[None, :] + sx[:, None] * right[None, :] + sy[:, None] * up[None, :]).astype(np.float32)
+    pick = rng.integers(0, len(pos) - 2, n_srf)                                     # (the last two faces are the light)
+    w = rng.dirichlet((1.0, 1.0, 1.0), n_srf).astype(np.float32)
+    o_srf = (pos[pick] * w[:, :, None]).sum(axis=1) + np.asarray([0.0, 0.01, 0.0], np.float32)
+    d_srf = rng.standard_normal((n_srf, 3), dtype=np.float32)
+    d_srf[:, 1] = np.abs(d_srf[:, 1]) * rng.uniform(0.0, 1.0, n_srf).astype(np.float32) ** 3      # many of them nearly horizontal
+    org = np.concatenate([o_vol, o_cam, o_srf]).astype(np.float32)
+    dirs = np.concatenate([d_vol, d_cam, d_srf]).astype(np.float32)
+    perm = rng.permutation(n)
+    return np.ascontiguousarray(org[perm]), np.ascontiguousarray(dirs[perm])
+
+
+def test_c4_scale_closest_hit_gate(pt, ob, terrain, gpu_device):
+    """SURVEY 8f-1's gate at C4 scale: on the 8.4 M-triangle terrain in the device form bench.py --config c4
+    runs (the quantised 4-wide nodes), the SAH walk's closest hit -- t bits and face -- equals the reference-topology walk's
+    (bvh.h:178-246: unpruned, origin-containing boxes, ~2.5e6 triangle tests per ray; both on the GPU) on PTAMD_GATE_RAYS
+    rays (default 1e6), and equals a CPU brute force over ALL triangles with the oracle's triangle test on the first
+    PTAMD_GATE_BRUTE of them (default 1e4)."""
+    import os
+    import time
+    n = int(os.environ.get("PTAMD_GATE_RAYS", "1000000"))
+    n_brute = min(n, int(os.environ.get("PTAMD_GATE_BRUTE", "10000")))
+    org, dirs = _gate_rays(terrain, n)
+    fb = pt.Framebuffer(pt.Resolution(8, 8))
+    sah_tr = pt.DevicePathTracer(0, 1, 1, (8, 8), terrain, fb, pt.CameraConfig(*TERRAIN_CAMERA), bvhMode=1)
+    sah_tr.renderTaskAsync(pt.RenderTask(8, 8, 0, 0)); sah_tr.waitForRenderTask()
+    form = sah_tr.kernelName()
+    assert "sahq" in form or "sahc" in form, form                  # the 8-bit-plane node forms (what C4 runs), not the 128-byte one
+    t0 = time.perf_counter()
+    t_sah, f_sah = sah_tr.katClosestHit(org, dirs)
+    t_sah_s = time.perf_counter() - t0
+    sah_tr.close()
+    ref_tr = pt.DevicePathTracer(0, 1, 1, (8, 8), terrain, fb, pt.CameraConfig(*TERRAIN_CAMERA), bvhMode=0)
+    t_ref, f_ref = np.empty_like(t_sah), np.empty_like(f_sah)
+    t0 = time.perf_counter()
+    chunk = 50_000                                                 # a launch of the unpruned walk stays in the seconds
+    for a in range(0, n, chunk):
+        t_ref[a:a + chunk], f_ref[a:a + chunk] = ref_tr.katClosestHit(org[a:a + chunk], dirs[a:a + chunk])
+    t_ref_s = time.perf_counter() - t0
+    ref_tr.close()
+    same = (t_ref.view(np.uint32) == t_sah.view(np.uint32)) & (f_ref == f_sah)
+    hits = int((f_ref >= 0).sum())
+    print("C4-scale gate (%s): %d of %d rays differ between the SAH walk (%.1f s) and the reference-topology walk (%.1f s); %d hit"
+          % (form, int((~same).sum()), n, t_sah_s, t_ref_s, hits))
+    assert int((~same).sum()) == 0
+    assert hits > n // 3
+    t0 = time.perf_counter()
+    t_b, f_b, ties = ob.brute_closest(terrain.triangles, org[:n_brute], dirs[:n_brute], threads=min(16, os.cpu_count() or 1))
+    miss = f_b < 0
+    got_t, got_f = t_sah[:n_brute], f_sah[:n_brute]
+    bad_t = np.where(miss, got_f >= 0, got_t.view(np.uint32) != t_b.view(np.uint32))
+    bad_f = (~miss) & (ties == 1) & (got_f != f_b)
+    print("brute force over all %d triangles, %d rays (%.1f s): %d differ in t, %d in the face; %d rays with tied faces"
+          % (len(terrain.triangles), n_brute, time.perf_counter() - t0, int(bad_t.sum()), int(bad_f.sum()), int((ties > 1).sum())))
+    assert int(bad_t.sum()) == 0 and int(bad_f.sum()) == 0

@@ -721,3 +721,27 @@ def test_band_queue_of_the_dqrb_policy(tmp_path):
     for w, h, t in ((1920, 1080, 8), (3840, 2160, 16), (400, 400, 3), (64, 36, 4), (16, 8, 2)):
         r = subprocess.run([exe, str(w), str(h), str(t)], capture_output=True, text=True)
         assert r.returncode == 0 and r.stdout.startswith("ok:"), (w, h, t, r.stdout, r.stderr)
+
+
+def test_stream_thread_teardown_is_deterministic_and_race_free(tmp_path):
+    """VERDICT r3 item 4 / ADVICE r3: the worker teardown race fixed in 6d7caea (a worker that tested `shouldTerminate`
+    after the frame-END barrier, as /root/reference/src/StreamThread.h:94-101 does, could leave while RenderManager::reset()
+    waited for it on the frame-START barrier) pinned on the CPU: the product's RenderManager.h / StreamThread.h / barrier.h
+    compiled against a stub of the C ABI (no HIP), worker 0 held for 300 ms right behind the frame-end barrier while
+    ~RenderManager() runs -- the interleaving that hung.  The current header must terminate (also under ThreadSanitizer,
+    with no report); the same program with the old check re-created in the header's test seam must hang (timeout)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "multi-gpu-path-tracer_amd", "csrc")
+    src = [os.path.join(ROOT, "tests", "native", "stream_thread_teardown_check.cpp"), os.path.join(csrc, "pt_common.cpp"), os.path.join(csrc, "pt_bvh.cpp")]
+    base = ["g++", "-O1", "-g", "-std=c++17", "-I", csrc, "-pthread"]
+    new, old, tsan = str(tmp_path / "teardown_new"), str(tmp_path / "teardown_old"), str(tmp_path / "teardown_tsan")
+    subprocess.run(base + ["-o", new] + src, check=True)
+    subprocess.run(base + ["-DOLD_CHECK_AFTER_FRAME_END", "-o", old] + src, check=True)
+    subprocess.run(base + ["-fsanitize=thread", "-o", tsan] + src, check=True)
+    for workers, frames in ((8, 3), (2, 1), (16, 2)):
+        r = subprocess.run([new, str(workers), str(frames)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and r.stdout.startswith("teardown ok"), (workers, frames, r.stdout, r.stderr)
+    r = subprocess.run([tsan, "8", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ThreadSanitizer" not in (r.stdout + r.stderr), (r.stdout, r.stderr[-3000:])
+    with pytest.raises(subprocess.TimeoutExpired):          # the pre-fix ordering deadlocks in this interleaving, every time
+        subprocess.run([old, "8", "3"], capture_output=True, text=True, timeout=5)

@@ -1,0 +1,286 @@
+// tools/tree_cost_model.cpp -- CPU model of what a ray segment costs the SAH kernel's memory path under different
+// device layouts of the SAH tree (C4 is bound by per-lane 16-byte requests).  Not product code.
+//
+//   g++ -O2 -std=c++17 -ffp-contract=off -Imulti-gpu-path-tracer_amd/csrc tools/tree_cost_model.cpp \
+//       multi-gpu-path-tracer_amd/csrc/{pt_bvh,pt_common,pt_scene_io,pt_jpeg}.cpp -lz -pthread -o build/tree_cost_model
+//   build/tree_cost_model [grid=2048] [paths=20000]
+//
+// It builds the product's own binary SAH tree (build_sah_bvh) of the C4 terrain, collapses it to K-wide nodes the way
+// collapse_sah_quads does (largest inner child first), quantises child boxes to 8-bit planes the way quantise_sah_quads
+// does, and walks a sample of C4's path segments (camera rays + mixture-sampled bounces, depth 8) through every variant
+// with the kernel's own rules (nearest child first, the others pushed unsorted, pruning by the closest hit at the visit,
+// no test at the pop): node visits, leaf visits, triangle tests and (lane, 16-byte) requests per segment.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "pt_internal.h"
+
+using namespace pt;
+
+struct V { double x, y, z; };
+static V operator+(V a, V b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static V operator-(V a, V b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static V operator*(double s, V a) { return {s * a.x, s * a.y, s * a.z}; }
+static double dot(V a, V b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static V cross(V a, V b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static V norm(V a) { double l = std::sqrt(dot(a, a)); return (1.0 / l) * a; }
+
+struct Tri { V v0, e1, e2, n; int mat; };
+struct Ray { V o, d; };
+
+struct Child { float b[6]; int node; uint32_t first, count; };      // node >= 0: inner; else leaf [first, first + count)
+struct WNode { std::vector<Child> ch; };
+
+struct Tree {
+    std::vector<WNode> nodes;
+    int K;
+};
+
+static float half_area(const float *b) { float ex = b[1] - b[0], ey = b[3] - b[2], ez = b[5] - b[4]; return ex * ey + ey * ez + ez * ex; }
+
+// collapse the pair tree into K-wide nodes (as collapse_sah_quads: replace the inner child with the largest box)
+static int collapse(const std::vector<NodePair> &pairs, uint32_t p, int K, Tree &T)
+{
+    const int id = (int)T.nodes.size();
+    T.nodes.emplace_back();
+    auto child = [&](uint32_t pi, int side) {
+        const NodePair &n = pairs[pi];
+        Child c;
+        const float *f = side ? &n.rxmin : &n.lxmin;
+        for (int k = 0; k < 6; k++) c.b[k] = f[k];
+        const uint32_t link = side ? n.rlink : n.llink, cnt = side ? n.rcnt : n.lcnt;
+        c.node = cnt ? -1 : (int)link; c.first = cnt ? link : 0; c.count = cnt;
+        return c;
+    };
+    std::vector<Child> ch{child(p, 0), child(p, 1)};
+    while ((int)ch.size() < K) {
+        int pick = -1; float best = -1.0f;
+        for (size_t i = 0; i < ch.size(); i++) {
+            if (ch[i].node < 0) continue;
+            const float a = half_area(ch[i].b);
+            if (pick < 0 || a > best) { pick = (int)i; best = a; }
+        }
+        if (pick < 0) break;
+        const uint32_t pp = (uint32_t)ch[(size_t)pick].node;
+        ch[(size_t)pick] = child(pp, 0);
+        ch.push_back(child(pp, 1));
+    }
+    std::vector<Child> kept;
+    for (Child &c : ch) if (c.b[0] <= c.b[1]) kept.push_back(c);
+    for (Child &c : kept) if (c.node >= 0) c.node = collapse(pairs, (uint32_t)c.node, K, T);
+    T.nodes[(size_t)id].ch = kept;
+    return id;
+}
+
+// 8-bit planes, power-of-two unit per axis, origin = the per-axis minimum, rounded outwards (quantise_sah_quads)
+static void quantise(Tree &T)
+{
+    for (WNode &n : T.nodes) {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (const Child &c : n.ch) for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], c.b[2 * a]); mx[a] = std::max(mx[a], c.b[2 * a + 1]); }
+        for (int a = 0; a < 3; a++) {
+            const float ext = mx[a] - mn[a];
+            int eb = -126;
+            if (ext > 0) { (void)std::frexp(ext / 255.0f, &eb); }
+            float unit = std::ldexp(1.0f, eb);
+            while (!(std::fmaf(255.0f, unit, mn[a]) >= mx[a])) unit *= 2.0f;
+            for (Child &c : n.ch) {
+                long bl = (long)std::floor((double)(c.b[2 * a] - mn[a]) / unit), bh = (long)std::ceil((double)(c.b[2 * a + 1] - mn[a]) / unit);
+                bl = std::min(std::max(bl, 0l), 255l); bh = std::min(std::max(bh, 0l), 255l);
+                while (bl > 0 && !(std::fmaf((float)bl, unit, mn[a]) <= c.b[2 * a])) bl--;
+                while (bh < 255 && !(std::fmaf((float)bh, unit, mn[a]) >= c.b[2 * a + 1])) bh++;
+                c.b[2 * a] = std::fmaf((float)bl, unit, mn[a]); c.b[2 * a + 1] = std::fmaf((float)bh, unit, mn[a]);
+            }
+        }
+    }
+}
+
+struct Cost { double visits = 0, leaves = 0, tris = 0, req = 0, stale = 0, maxsp = 0, boxes = 0; };
+struct Layout { const char *name; int node_bytes; int tri_bytes; bool packed_leaf; bool prune_pop; bool full_sort; };
+
+static bool mt(const Tri &t, const Ray &r, double tmin, double tmax, double &tout)
+{
+    const V p = cross(r.d, t.e2);
+    const double det = dot(t.e1, p);
+    if (std::fabs(det) <= 1e-8) return false;
+    const double inv = 1.0 / det;
+    const V tv = r.o - t.v0;
+    const double u = dot(tv, p) * inv;
+    if (u < 0 || u > 1) return false;
+    const V q = cross(tv, t.e1);
+    const double v = dot(r.d, q) * inv;
+    if (v < 0 || u + v > 1) return false;
+    const double tt = dot(t.e2, q) * inv;
+    if (!(tt < tmax && tt > tmin)) return false;
+    tout = tt;
+    return true;
+}
+
+static int walk(const Tree &T, const std::vector<Tri> &tris, const Ray &r, const Layout &L, Cost &C, double &t_hit)
+{
+    struct Ent { int node; uint32_t first, count; float tn; };
+    Ent stack[256];
+    int sp = 0;
+    double tbest = INFINITY;
+    int best = -1;
+    const double ix = 1.0 / r.d.x, iy = 1.0 / r.d.y, iz = 1.0 / r.d.z;
+    Ent cur{0, 0, 0, 0.0f};
+    bool have = true;
+    while (have) {
+        if (cur.node >= 0) {
+            const WNode &n = T.nodes[(size_t)cur.node];
+            C.visits++;
+            C.req += L.node_bytes / 16;
+            C.boxes += (double)n.ch.size();
+            Ent hit[16]; int nh = 0;
+            for (const Child &c : n.ch) {
+                const double t1 = (c.b[0] - r.o.x) * ix, t2 = (c.b[1] - r.o.x) * ix, t3 = (c.b[2] - r.o.y) * iy, t4 = (c.b[3] - r.o.y) * iy;
+                const double t5 = (c.b[4] - r.o.z) * iz, t6 = (c.b[5] - r.o.z) * iz;
+                const double tn = std::fmax(std::fmax(std::fmin(t1, t2), std::fmin(t3, t4)), std::fmin(t5, t6));
+                const double tf = std::fmin(std::fmin(std::fmax(t1, t2), std::fmax(t3, t4)), std::fmax(t5, t6));
+                if (tf >= std::fmax(tn, 0.0) && tn <= tbest) hit[nh++] = Ent{c.node, c.first, c.count, (float)tn};
+            }
+            if (nh == 0) { C.stale += cur.tn > 0 ? 0 : 0; }
+            if (L.full_sort) std::sort(hit, hit + nh, [](const Ent &a, const Ent &b) { return a.tn < b.tn; });
+            else for (int i = 1; i < nh; i++) if (hit[i].tn < hit[0].tn) std::swap(hit[0], hit[i]);
+            for (int i = nh - 1; i >= 1; i--) stack[sp++] = hit[i];
+            C.maxsp = std::max(C.maxsp, (double)sp);
+            if (nh > 0) { cur = hit[0]; continue; }
+        } else {
+            C.leaves++;
+            C.tris += cur.count;
+            C.req += L.packed_leaf ? (cur.count * (uint32_t)L.tri_bytes + 15) / 16 : cur.count * (((uint32_t)L.tri_bytes + 15) / 16);
+            for (uint32_t k = 0; k < cur.count; k++) {
+                double tt;
+                if (mt(tris[cur.first + k], r, 0.001, tbest, tt)) { tbest = tt; best = (int)(cur.first + k); }
+            }
+        }
+        have = false;
+        while (sp > 0) {
+            cur = stack[--sp];
+            if (L.prune_pop && cur.tn > tbest) continue;
+            have = true;
+            break;
+        }
+    }
+    t_hit = tbest;
+    return best;
+}
+
+int main(int argc, char **argv)
+{
+    const unsigned grid = argc > 1 ? (unsigned)atoi(argv[1]) : 2048;
+    const int n_paths = argc > 2 ? atoi(argv[2]) : 20000;
+    pt_host_scene *hs = nullptr;
+    if (pt_scene_make_terrain(grid, &hs) != PT_OK) { fprintf(stderr, "terrain: %s\n", pt_last_error_string()); return 1; }
+    const size_t n = pt_scene_triangle_count(hs);
+    const pt_triangle *pts = pt_scene_triangles(hs);
+    const pt_material *mats = pt_scene_materials(hs);
+    std::vector<float> pos(9 * n);
+    for (size_t i = 0; i < n; i++) { memcpy(&pos[9 * i], pts[i].v0.position, 12); memcpy(&pos[9 * i + 3], pts[i].v1.position, 12); memcpy(&pos[9 * i + 6], pts[i].v2.position, 12); }
+    std::vector<int> lights;
+    for (size_t i = 0; i < n; i++) if (mats[pts[i].materialIdx].emissiveFactor[0] > 0.0001f) lights.push_back((int)i);
+    printf("terrain grid %u: %zu triangles, %zu light triangles\n", grid, n, lights.size());
+
+    auto face_tri = [&](int f) {
+        Tri t;
+        const float *p = &pos[9 * (size_t)f];
+        const V a{p[0], p[1], p[2]}, b{p[3], p[4], p[5]}, c{p[6], p[7], p[8]};
+        t.v0 = a; t.e1 = b - a; t.e2 = c - a; t.n = norm(cross(t.e1, t.e2)); t.mat = pts[f].materialIdx;
+        return t;
+    };
+
+    struct Variant { int K; uint32_t max_leaf; bool quant; Layout L; };
+    std::vector<Variant> variants = {
+        {4, 4, false, {"K4 leaf4 fp32 128B / tri 48B (sahw)", 112, 48, false, false, false}},
+        {4, 4, true,  {"K4 leaf4 q8   64B / tri 48B (sahq = r03)", 64, 48, false, false, false}},
+        {4, 4, true,  {"K4 leaf4 q8   48B / tri 48B", 48, 48, false, false, false}},
+        {4, 4, true,  {"K4 leaf4 q8   48B / tri 40B packed", 48, 40, true, false, false}},
+        {4, 4, true,  {"K4 leaf4 q8   48B / tri 36B packed", 48, 36, true, false, false}},
+        {4, 4, true,  {"K4 leaf4 q8   48B / 36B packed, prune at pop", 48, 36, true, true, false}},
+        {4, 4, true,  {"K4 leaf4 q8   48B / 36B packed, full sort", 48, 36, true, false, true}},
+        {4, 2, true,  {"K4 leaf2 q8   48B / tri 36B packed", 48, 36, true, false, false}},
+        {4, 1, true,  {"K4 leaf1 q8   48B / tri 36B", 48, 36, true, false, false}},
+        {4, 8, true,  {"K4 leaf8 q8   48B / tri 36B packed", 48, 36, true, false, false}},
+        {8, 4, true,  {"K8 leaf4 q8   80B / tri 48B", 80, 48, false, false, false}},
+        {8, 4, true,  {"K8 leaf4 q8   80B / tri 36B packed", 80, 36, true, false, false}},
+        {8, 4, true,  {"K8 leaf4 q8   80B / 36B packed, prune at pop", 80, 36, true, true, false}},
+        {8, 4, true,  {"K8 leaf4 q8   80B / 36B packed, full sort", 80, 36, true, false, true}},
+        {8, 2, true,  {"K8 leaf2 q8   80B / tri 36B packed", 80, 36, true, false, false}},
+        {8, 1, true,  {"K8 leaf1 q8   80B / tri 36B", 80, 36, true, false, false}},
+        {8, 1, true,  {"K8 leaf1 q8   80B / tri 36B, prune at pop", 80, 36, true, true, false}},
+        {8, 8, true,  {"K8 leaf8 q8   80B / tri 36B packed", 80, 36, true, false, false}},
+    };
+
+    // segments: traced once through the first variant's tree (any tree gives the same closest hits)
+    std::vector<Ray> segs;
+    uint32_t cached_leaf = 0;
+    SahBvh sb;
+    std::vector<Tri> tris;
+    Tree T;
+    auto prepare = [&](int K, uint32_t max_leaf, bool quant) {
+        if (cached_leaf != max_leaf) {
+            build_sah_bvh(pos.data(), n, sb, max_leaf);
+            tris.resize(n);
+            for (size_t s = 0; s < n; s++) tris[s] = face_tri(sb.order[s]);
+            cached_leaf = max_leaf;
+        }
+        T = Tree(); T.K = K;
+        collapse(sb.pairs, 0, K, T);
+        if (quant) quantise(T);
+    };
+    prepare(4, 4, false);
+    {
+        // camera (bench.py TERRAIN_CAMERA, camera_basis)
+        const V from{0.0, 220.0, 620.0}, front{0.0, -0.35, -1.0};
+        const double hh = std::tan(45.0 * M_PI / 180 / 2), hw = hh;
+        const V w = norm((-1.0) * front), u = norm(cross(V{0, 1, 0}, w)), v = cross(w, u);
+        const V llc = from - hw * u - hh * v - w, hor = (2 * hw) * u, ver = (2 * hh) * v;
+        std::mt19937_64 rng(1984);
+        std::uniform_real_distribution<double> U(0.0, 1.0);
+        const Layout L0 = variants[0].L;
+        std::vector<Tri> ltris;
+        for (int f : lights) ltris.push_back(face_tri(f));
+        for (int p = 0; p < n_paths; p++) {
+            Ray r{from, llc + U(rng) * hor + U(rng) * ver - from};
+            for (int depth = 0; depth < 8; depth++) {
+                segs.push_back(r);
+                Cost c; double t;
+                const int hit = walk(T, tris, r, L0, c, t);
+                if (hit < 0 || tris[(size_t)hit].mat == 1) break;
+                const V hp = r.o + t * r.d, nn = tris[(size_t)hit].n;
+                V nd;
+                if (U(rng) < 0.5) {
+                    const Tri &lt = ltris[(size_t)(U(rng) * ltris.size()) % ltris.size()];
+                    const double s1 = std::sqrt(U(rng)), r2 = U(rng);
+                    const V lp = lt.v0 + (s1 * (1 - r2)) * lt.e1 + (s1 * r2) * lt.e2;      // (not the reference's exact form: a sample is a sample)
+                    nd = lp - hp;
+                } else {
+                    const double r1 = U(rng), r2 = U(rng), phi = 2 * M_PI * r1;
+                    const V a = std::fabs(nn.x) > 0.9 ? V{0, 1, 0} : V{1, 0, 0};
+                    const V b1 = norm(cross(nn, a)), b0 = cross(nn, b1);
+                    nd = (std::cos(phi) * 2 * std::sqrt(r2)) * b0 + (std::sin(phi) * 2 * std::sqrt(r2)) * b1 + std::sqrt(1 - r2) * nn;
+                }
+                r = Ray{hp, nd};
+            }
+        }
+        printf("%d paths -> %zu segments (%.3f per path)\n", n_paths, segs.size(), (double)segs.size() / n_paths);
+    }
+    printf("%-52s %8s %8s %8s %8s %8s %8s %9s %6s\n", "variant (per segment)", "nodes", "visits", "boxes", "leaves", "tris", "req16", "node MB", "stack");
+    for (const Variant &vr : variants) {
+        prepare(vr.K, vr.max_leaf, vr.quant);
+        Cost c;
+        for (const Ray &r : segs) { double t; (void)walk(T, tris, r, vr.L, c, t); }
+        const double s = (double)segs.size();
+        printf("%-52s %8zu %8.2f %8.2f %8.2f %8.2f %8.2f %9.1f %6.0f\n", vr.L.name, T.nodes.size(), c.visits / s, c.boxes / s, c.leaves / s, c.tris / s, c.req / s,
+               (double)T.nodes.size() * vr.L.node_bytes / 1e6, c.maxsp);
+        fflush(stdout);
+    }
+    pt_scene_free(hs);
+    return 0;
+}
