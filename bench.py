@@ -403,6 +403,10 @@ def main():
     # max over ranks of the timed region; sum over ranks of the exact work counters
     cnt = mgr.tracer.readCounters()
     kernel_ms, launches = mgr.tracer.kernelTime()
+    try:
+        split_tiles = mgr.tracer.splitTiles()
+    except Exception:
+        split_tiles = None
     keys = ["paths", "segments", "box_tests", "tri_tests", "light_tests"]
     if world > 1:
         rdev = "cpu" if args.rehearse else "cuda"
@@ -466,6 +470,7 @@ def main():
             "segments_per_path": total["segments"] / max(total["paths"], 1),
             "tests_per_segment": {k: total[k] / max(total["segments"], 1) for k in ("box_tests", "tri_tests", "light_tests")},
             "kernel_build_id": kernel_build_id(),
+            "split_tiles_next_launch": split_tiles,      # tiles the schedule hands to several waves each (0: none is critical)
             # N > 1: whole-frame counters over the slowest rank's kernel time (per-launch profile counts are those of a
             # whole-frame launch and do not apply to a 1/N share, so `achieved` stays null there)
             "roofline": roofline_block(args.config, desc if world == 1 else desc + " [1/%d shares]" % world, total,

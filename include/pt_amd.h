@@ -317,6 +317,10 @@ PT_API pt_status pt_kat_exhaustive(pt_device *dev, int op, uint32_t first_bits, 
  * t (or -1 on miss) and the face index in the uploaded triangle order (-1 on miss).     */
 PT_API pt_status pt_kat_closest_hit(pt_device *dev, const float *origins, const float *dirs,
                                     float *t_out, int *face_out, size_t n);
+/* Diagnostic companion of pt_kat_closest_hit: the same walk, and per ray how many box and triangle tests it took
+ * (either output may be NULL).  Wave-uniform walks (big reference trees) report wave totals in every lane.  */
+PT_API pt_status pt_kat_walk_cost(pt_device *dev, const float *origins, const float *dirs,
+                                  uint32_t *box_tests_out, uint32_t *tri_tests_out, size_t n);
 
 /* --------------------------------------------------------------- scene I/O (host) -- */
 /* SceneLoader::load(std::string&), HostScene.cpp:98-139, for glTF 2.0 input: a .glb container or .gltf

@@ -402,7 +402,7 @@ __device__ unsigned long long g_occ[8];
 // tree gets the top levels and whole stacks, a tree beyond the caches the short stack and no top levels -- because a lone
 // wave's chain of dependent micro-steps is what bounds a rank's share of a frame, and generality costs instructions in it
 // (an eighth of the duck's frame: 47.4 ms with everything decided at run time, 43.9 ms with round 2's kernel).
-template <int kForm, int kTop = 2, int kSpill = 2, bool kCoop = false>
+template <int kForm, int kTop = 2, int kSpill = 2>
 __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 {
     extern __shared__ float4 lds_raw[];
@@ -420,14 +420,6 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
                             P.counters + 5,
 #endif
                             V.end, (uint32_t)(P.top_records * P.top_record_bytes)};
-    // cooperative record fetch (pt_walk.h CoopView): per wave 64 offset slots and a 4 KB staging area, behind the top levels
-    CoopView C = {nullptr, nullptr};
-    if (kCoop) {
-        float4 *coop_base = V.end + (size_t)P.top_records * (size_t)(P.top_record_bytes / 16);
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        C.slot = reinterpret_cast<uint32_t *>(coop_base + (size_t)wave * (kCoopLdsPerWave / 16));
-        C.buf = coop_base + (size_t)wave * (kCoopLdsPerWave / 16) + 16;
-    }
     if (kTop != 0 && P.top_records > 0) {                  // the tree's top levels, once per workgroup of the persistent launch
         const float4 *gn = reinterpret_cast<const float4 *>(P.nodes);
         const int n4 = P.top_records * (P.top_record_bytes / 16);
@@ -514,11 +506,7 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
                     occ[4] += (unsigned long long)(64 - run - lose - waiting);
                 }
 #endif
-                if (kCoop) {
-                    // every lane of the wave fetches pieces of the records the chosen lanes asked for (pt_walk.h)
-                    if (want_tri >= want_node) sahw_tri_step_coop<kSpill>(P, C, lane, W.n0 != 0, tri_mask, W, L.ro, L.rd, 0.001f, stack, L.n_tri);
-                    else sahq_node_step_coop<kSpill>(P, C, lane, sah_wants_node(W), pair_mask & ~tri_mask, W, L.ro, stack, L.n_box);
-                } else if (want_tri >= want_node) {
+                if (want_tri >= want_node) {
                     if (sah_wants_tri(W)) {
                         if (kForm != 0) (void)sahw_tri_step<kSpill>(P, W, L.ro, L.rd, 0.001f, stack, L.n_tri);
                         else (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
@@ -588,8 +576,6 @@ __global__ __launch_bounds__(kBlock) void render_kernel_sahw(RenderParams P) { r
 __global__ __launch_bounds__(kBlock) void render_kernel_sahw_lean(RenderParams P) { render_sah_body<1, 0, 0>(P); }
 // the 4-wide form in 64-byte records (RenderParams::sah == 3), trees beyond the caches: short LDS stack + overflow area
 __global__ __launch_bounds__(kBlock) void render_kernel_sahq(RenderParams P) { render_sah_body<2, 0, 1>(P); }
-// ... with the cooperative record fetch (pt_walk.h CoopView; RenderParams::coop): what C4 runs
-__global__ __launch_bounds__(kBlock) void render_kernel_sahq_coop(RenderParams P) { render_sah_body<2, 0, 1, true>(P); }
 // either form with both options decided per launch (PTAMD_SAH_TOP / PTAMD_SAH_STACK / PTAMD_SAH_QUANT set by hand, and the tests)
 __global__ __launch_bounds__(kBlock) void render_kernel_sahw_any(RenderParams P) { render_sah_body<1, 2, 2>(P); }
 __global__ __launch_bounds__(kBlock) void render_kernel_sahq_any(RenderParams P) { render_sah_body<2, 2, 2>(P); }
@@ -736,8 +722,11 @@ __global__ void kat_exhaustive_kernel(int op, uint32_t first, uint64_t count, un
     if (bad) atomicAdd(&n_bad[0], bad);
 }
 
+// uniform: the reference tree through the wave-uniform stack walk (traverse_uniform_stack: the same tests per ray in the same
+// order as the per-lane walk, triangle and node records through the scalar cache): what makes a million rays through the
+// unpruned walk of an 8 M-triangle reference tree a matter of seconds (the C4-scale gate, tests/test_gpu_c4.py).
 __global__ void kat_hit_kernel(RenderParams P, const float *org, const float *dir, float *t_out,
-                               int *face_out, size_t n)
+                               int *face_out, size_t n, int uniform, uint32_t *box_out, uint32_t *tri_out)
 {
     extern __shared__ float4 lds_raw[];
     const LdsLayout L = lds_carve<false>(P, lds_raw, (int)blockDim.x);
@@ -748,14 +737,18 @@ __global__ void kat_hit_kernel(RenderParams P, const float *org, const float *di
     v3 o = mk3(org[3 * k], org[3 * k + 1], org[3 * k + 2]);
     v3 d = mk3(dir[3 * k], dir[3 * k + 1], dir[3 * k + 2]);
     uint32_t nb = 0, nt = 0;
+    unsigned long long wb = 0, wt = 0;
     Hit h = P.sah ? traverse_sah(P, o, d, 0.001f, 3.402823466e+38f, L.stack + threadIdx.x, (int)blockDim.x, nb, nt)
+          : uniform ? traverse_uniform_stack<1>(P, o, d, 0.001f, 3.402823466e+38f, L.stack + threadIdx.x, (int)blockDim.x, wb, wt)
                   : traverse<false, false>(S, o, d, 0.001f, 3.402823466e+38f, L.stack + threadIdx.x,
                                            reinterpret_cast<uint2 *>(L.queue) + threadIdx.x, (int)blockDim.x, P.queue_entries, nb, nt);
     if (live) {
-        t_out[i] = h.slot >= 0 ? h.t : -1.0f;
+        if (t_out) t_out[i] = h.slot >= 0 ? h.t : -1.0f;
         int face = -1;
         if (h.slot >= 0) face = P.shade[h.slot].face;
-        face_out[i] = face;
+        if (face_out) face_out[i] = face;
+        if (box_out) box_out[i] = uniform ? (uint32_t)wb : nb;
+        if (tri_out) tri_out[i] = uniform ? (uint32_t)wt : nt;
     }
 }
 
@@ -911,8 +904,6 @@ struct pt_device {
     int lean_pct = 100;           // SAH tree, cache-resident: launches of up to this % of the device's wave slots take the lean kernel (PTAMD_LEAN_PCT)
     bool deal_dense = true;       // dealt mask walk: the 8-wave build for launches of more than 2 x the device's wave slots (PTAMD_DEAL_DENSE=0: never)
     int resident_cap = 0;         // persistent kernels: at most this many workgroups per CU (PTAMD_RESIDENT; 0 = what fits)
-    bool sah_coop = true;         // 64-byte-node SAH kernel: cooperative record fetch through LDS (PTAMD_SAH_COOP=0: every lane fetches its own records)
-    int coop_stack_lds = 0;       // ... LDS stack entries with it (PTAMD_COOP_STACK; 0 = sah_stack_lds)
     int sah_stack_lds = 16;       // persistent SAH kernel: stack entries per lane kept in LDS, deeper ones spill to device memory (PTAMD_SAH_STACK: 0 = all in LDS, else 11..64)
     struct Resident { const void *kern; size_t lds; int blocks; };
     std::vector<Resident> resident_blocks;      // per kernel and LDS size: workgroups one CU holds (persistent grids)
@@ -1031,8 +1022,6 @@ try {
     if (const char *e = getenv("PTAMD_PART_LANES")) d->part_lanes = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_SAH_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) d->sah_split = v; }
     if (const char *e = getenv("PTAMD_SAH_STACK")) { const int v = atoi(e); if (v == 0 || (v >= 11 && v <= 64)) { d->sah_stack_lds = v; d->sah_by_hand = true; } }
-    if (const char *e = getenv("PTAMD_SAH_COOP")) d->sah_coop = atoi(e) != 0;
-    if (const char *e = getenv("PTAMD_COOP_STACK")) { const int v = atoi(e); if (v >= 8 && v <= 64) d->coop_stack_lds = v; }
     if (const char *e = getenv("PTAMD_LEAN_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 1000) d->lean_pct = v; }
     if (const char *e = getenv("PTAMD_DEAL_DENSE")) d->deal_dense = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_RESIDENT")) { const int v = atoi(e); if (v >= 1 && v <= 16) d->resident_cap = v; }
@@ -1467,7 +1456,6 @@ static size_t lds_bytes(const RenderParams &P, int block, bool stage)
     f4 += ((size_t)P.queue_entries * block * P.queue_dwords + 3) / 4;
     if (P.shade_lds) f4 += (P.shade_lds == 1 ? (size_t)P.n_tris * 3 : 0) + (size_t)P.n_mats * 3 + (size_t)P.n_lights * 5;
     f4 += (size_t)P.top_records * (size_t)(P.top_record_bytes / 16);
-    if (P.coop) f4 += (size_t)(block / dev::kWave) * (size_t)(dev::kCoopLdsPerWave / 16);       // render_sah_body's CoopView
     if (P.deal_cap > 0 && P.stack_entries == 0)       // dev::deal_carve (kWalk 4: no stack)
         f4 += (size_t)P.n_tris * 3 /* onb table, stage_shade_lds */ + (size_t)P.n_tris * 3 +
               (size_t)(block / dev::kWave) * (2 * (size_t)dev::kWave + ((size_t)P.deal_cap * 2 + 15) / 16) +
@@ -1506,7 +1494,7 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.legacy_mats = dev->d_legacy; P.spheres = dev->d_spheres; P.n_spheres = dev->n_spheres;
     // SAH walks check for room before they push (SahStack): with the whole stack in LDS the check must never fire, hence + 3
     P.stack_spill = nullptr; P.spill_blocks = 0; P.stack_cap = 0x3fffffff;      // whole stack in LDS: the check never fires
-    P.top_records = 0; P.top_record_bytes = 64; P.coop = 0;
+    P.top_records = 0; P.top_record_bytes = 64;
     if (dev->sah) P.stack_entries = (int)dev->sah_stack;
     P.queue_dwords = (dev->packed_queue && !dev->legacy_on) ? 1 : 2;      // the extension kernel uses the unpacked queue
     P.n_mats = (int)dev->n_mats;
@@ -1574,9 +1562,8 @@ static TileSchedule *schedule_for(pt_device *dev, const RenderParams &P, unsigne
 typedef void (*RenderKernel)(RenderParams);
 struct KernelChoice { RenderKernel fn; const char *name; };
 #define PT_KERNEL(...) KernelChoice{__VA_ARGS__, "pt::" #__VA_ARGS__}
-static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool stage, bool packed, bool lean = false, bool dense = false, bool fetch_coop = false)
+static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool stage, bool packed, bool lean = false, bool dense = false)
 {
-    if (fetch_coop) return PT_KERNEL(dev::render_kernel_sahq_coop);
     if (lean) return PT_KERNEL(dev::render_kernel_sahw_lean);
     if (dense && walk == 4 && dev->deal_min <= 64) return PT_KERNEL(dev::render_kernel_dealt8);
     if (dense && walk == 5 && !coop) return PT_KERNEL(dev::render_kernel_dealt_stack6);
@@ -1674,9 +1661,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         const long long slots = (long long)dev->cu_count * resident_per_cu(dev, (const void *)dev::render_kernel_sahw_lean, lds_lean) * dev::kWavesPerBlock;
         lean = tiles * 100ll <= slots * (long long)dev->lean_pct;
     }
-    const bool fetch_coop = walk == 3 && dev->sah_persistent && dev->sah_quant_on && !dev->sah_by_hand && dev->sah_coop;
-    const int stack_lds = fetch_coop && dev->coop_stack_lds > 0 ? dev->coop_stack_lds : dev->sah_stack_lds;
-    P.coop = fetch_coop ? 1 : 0;
+    const int stack_lds = dev->sah_stack_lds;
     const bool short_stack = !lean;
     const bool top_levels = !lean && (dev->sah_by_hand || !dev->sah_quant_on);
     if (walk == 3 && dev->sah_persistent && short_stack && stack_lds > 0 && (int)dev->sah_stack > stack_lds) {
@@ -1694,7 +1679,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         P.top_record_bytes = dev->sah_quant_on ? 64 : 128;
     }
     const size_t lds = lds_bytes(P, dev::kBlock, stage);
-    const KernelChoice choice = pick_kernel(dev, walk, coop, stage, packed, lean, dense, fetch_coop);
+    const KernelChoice choice = pick_kernel(dev, walk, coop, stage, packed, lean, dense);
     const RenderKernel kern = choice.fn;
     {
         const pt_status st = ensure_lds(dev, (const void *)kern, lds);
@@ -2602,35 +2587,54 @@ try {
     return PT_OK;
 } PT_CATCH_ALL
 
-pt_status pt_kat_closest_hit(pt_device *dev, const float *org, const float *dirs, float *t_out, int *face_out, size_t n)
-try {
+static pt_status kat_walk(pt_device *dev, const float *org, const float *dirs, float *t_out, int *face_out, uint32_t *box_out, uint32_t *tri_out, size_t n)
+{
     clear_error();
-    if (!dev || !org || !dirs || !t_out || !face_out) return set_error(PT_ERR_INVALID, "null argument");
+    if (!dev || !org || !dirs) return set_error(PT_ERR_INVALID, "null argument");
     if (!dev->has_scene) return set_error(PT_ERR_NO_SCENE, "no scene uploaded");
     if (n == 0) return PT_OK;
     PT_HIP(hipSetDevice(dev->index));
     RenderParams P;
     memset(&P, 0, sizeof P);
     fill_params(dev, P);
-    float *dorg = nullptr, *ddir = nullptr, *dt = nullptr; int *df = nullptr;
+    float *dorg = nullptr, *ddir = nullptr, *dt = nullptr; int *df = nullptr; uint32_t *db = nullptr, *dn = nullptr;
     DevBufs bufs;
     PT_HIP(bufs.alloc((void **)&dorg, n * 12)); PT_HIP(bufs.alloc((void **)&ddir, n * 12));
     PT_HIP(bufs.alloc((void **)&dt, n * 4)); PT_HIP(bufs.alloc((void **)&df, n * 4));
+    if (box_out) PT_HIP(bufs.alloc((void **)&db, n * 4));
+    if (tri_out) PT_HIP(bufs.alloc((void **)&dn, n * 4));
     PT_HIP(hipMemcpy(dorg, org, n * 12, hipMemcpyHostToDevice));
     PT_HIP(hipMemcpy(ddir, dirs, n * 12, hipMemcpyHostToDevice));
     unsigned blocks = (unsigned)((n + 255) / 256);
     P.queue_dwords = 2; P.shade_lds = 0;
+    // a big reference tree (beyond the stack walk's 4 096 inner nodes, where rendering takes the per-lane walk): the wave-uniform
+    // walk is the only one that gets through ~2.5e6 triangle tests per ray in reasonable time
+    const int uniform = (!dev->sah && dev->n_pairs > 4096) ? 1 : 0;
+    if (uniform) P.queue_entries = 0;
     size_t lds = lds_bytes(P, 256, false);
     {
         const pt_status st = ensure_lds(dev, (const void *)dev::kat_hit_kernel, lds);
         if (st != PT_OK) return st;
     }
-    hipLaunchKernelGGL(dev::kat_hit_kernel, dim3(blocks), dim3(256), lds, 0, P, dorg, ddir, dt, df, n);
+    hipLaunchKernelGGL(dev::kat_hit_kernel, dim3(blocks), dim3(256), lds, 0, P, dorg, ddir, dt, df, n, uniform, db, dn);
     PT_HIP(hipGetLastError());
     PT_HIP(hipDeviceSynchronize());
-    PT_HIP(hipMemcpy(t_out, dt, n * 4, hipMemcpyDeviceToHost));
-    PT_HIP(hipMemcpy(face_out, df, n * 4, hipMemcpyDeviceToHost));
+    if (t_out) PT_HIP(hipMemcpy(t_out, dt, n * 4, hipMemcpyDeviceToHost));
+    if (face_out) PT_HIP(hipMemcpy(face_out, df, n * 4, hipMemcpyDeviceToHost));
+    if (box_out) PT_HIP(hipMemcpy(box_out, db, n * 4, hipMemcpyDeviceToHost));
+    if (tri_out) PT_HIP(hipMemcpy(tri_out, dn, n * 4, hipMemcpyDeviceToHost));
     return PT_OK;
+}
+
+pt_status pt_kat_closest_hit(pt_device *dev, const float *org, const float *dirs, float *t_out, int *face_out, size_t n)
+try {
+    if (!t_out || !face_out) { clear_error(); return set_error(PT_ERR_INVALID, "null argument"); }
+    return kat_walk(dev, org, dirs, t_out, face_out, nullptr, nullptr, n);
+} PT_CATCH_ALL
+
+pt_status pt_kat_walk_cost(pt_device *dev, const float *org, const float *dirs, uint32_t *box_out, uint32_t *tri_out, size_t n)
+try {
+    return kat_walk(dev, org, dirs, nullptr, nullptr, box_out, tri_out, n);
 } PT_CATCH_ALL
 
 } // extern "C"

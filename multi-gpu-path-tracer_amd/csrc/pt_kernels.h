@@ -49,7 +49,6 @@ struct RenderParams {
     int spill_blocks;                 // ... blocks of 8 entries per lane in it
     int top_records;                  // persistent SAH kernel: the first records of `nodes` (the tree's top levels) staged in LDS, or 0
     int top_record_bytes;             // ... 64 or 128 bytes each
-    int coop;                         // persistent SAH kernel: cooperative record fetch through LDS (pt_walk.h CoopView)
     int queue_entries;                // per-lane LDS leaf-queue slots (>= 2; 0 for the wave-uniform walks)
     int queue_dwords;                 // dwords per queue entry (1 packed, 2 otherwise)
     int n_pairs, n_tris;              // array lengths (for LDS staging)

@@ -1006,6 +1006,10 @@ __device__ __forceinline__ bool sahw_tri_step(const RenderParams &P, SahWalk &W,
 __device__ __forceinline__ void sahw_slab(float xmin, float xmax, float ymin, float ymax, float zmin, float zmax, v3 o, v3 inv, float tbest,
                                           float &key)
 {
+    // (Packed v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 would halve these twelve instructions and the decode's, and compile
+    // cleanly from two-element vectors -- 215 -> 173 VALU instructions per QuadQ visit -- but on gfx950 a packed f32
+    // instruction issues several times slower than the two scalar ones it replaces (MI355X_MICROARCH.md constants table;
+    // round 1's SLP measurement: C2 98 -> 118 ms), so they stay scalar.)
     const float t1 = (xmin - o.x) * inv.x, t2 = (xmax - o.x) * inv.x, t3 = (ymin - o.y) * inv.y, t4 = (ymax - o.y) * inv.y;
     const float t5 = (zmin - o.z) * inv.z, t6 = (zmax - o.z) * inv.z;
     const float tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
@@ -1074,7 +1078,6 @@ __device__ __forceinline__ void sahq_slab(uint32_t lo, uint32_t hi, float ox, fl
     key = present ? k : __builtin_inff();
 }
 
-// What a visit does with the record once it is in registers (shared by the own-lane and the cooperative fetch).
 template <int kSpill>
 __device__ __forceinline__ void sahq_node_eval(SahWalk &W, v3 o, const SahStack &S, float4 q0, float4 q1, float4 q2, float4 lk, uint32_t &n_box)
 {
@@ -1114,112 +1117,6 @@ __device__ __forceinline__ bool sahq_node_step(const RenderParams &P, SahWalk &W
     }
     sahq_node_eval<kSpill>(W, o, S, q0, q1, q2, lk, n_box);
     return sah_walking(W);
-}
-
-// ---- cooperative record fetch (the walks of trees beyond the caches) -----------------------------------------------------
-// What the vector-memory path charges a divergent gather (tools/ta_gather_bench.hip, profiles/r04_ta_gather.txt): a
-// wave-instruction costs ~16 cycles plus ~0.5 per active lane whatever its width, so a lane that fetches its own 64-byte
-// node with four dwordx4 pays four times; four ADJACENT lanes that fetch the four 16-byte pieces of one record are merged
-// by the address coalescer into one line request -- 0.22 records per clock and CU with 24 rays per wave the old way,
-// 0.54 this way.  So the lanes that take a micro-step first publish their record offsets, compacted, in the wave's LDS
-// slots; then ALL 64 lanes fetch pieces: lane l the piece l % kPieces of ray l / kPieces, by global_load_lds_dwordx4 (the
-// LDS destination of that instruction is lane-linear, which is exactly record-major here), one instruction per
-// 64 / kPieces rays; the owners read their records back with ds_read_b128.  Same records, same arithmetic afterwards.
-struct CoopView {
-    uint32_t *slot;               // this wave's 64 dwords: byte offset | 16-byte pieces wanted, of the fetch's rays, compacted
-    float4 *buf;                  // this wave's staging area, kCoopBuf float4 (64 node records, or 20 leaves of 4 triangles)
-};
-constexpr int kCoopBuf = 256;
-constexpr int kCoopLdsPerWave = 64 * 4 + kCoopBuf * 16;      // bytes; mirrored by lds_bytes() on the host
-
-__device__ __forceinline__ void coop_wait()
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // an LDS-DMA is a pending LDS write on the VM counter
-    wave_lds_fence();
-}
-
-// All 64 lanes call.  Rays first .. first + n_rays - 1 of the compacted order (n_rays * kPieces <= kCoopBuf): ray j's record
-// lands at C.buf + (j / kRays) * 64 + (j % kRays) * kPieces, kRays = 64 / kPieces.
-template <int kPieces>
-__device__ __forceinline__ void coop_issue(const CoopView &C, const char *base, int lane, int first, int n_rays)
-{
-    constexpr int kRays = 64 / kPieces;
-    const int sub = lane / kPieces, piece = lane - sub * kPieces;
-    for (int r0 = 0; r0 < n_rays; r0 += kRays) {          // wave-uniform
-        const int ray = r0 + sub;
-        if (sub < kRays && ray < n_rays) {
-            const uint32_t w = C.slot[first + ray];
-            if ((uint32_t)piece < (w & 15u))
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (size_t)(w & ~15u) + (size_t)piece * 16u),
-                                                 (__attribute__((address_space(3))) void *)(C.buf + (r0 / kRays) * 64), 16, 0, 0);
-        }
-    }
-}
-template <int kPieces>
-__device__ __forceinline__ const float4 *coop_record(const CoopView &C, int j)
-{
-    constexpr int kRays = 64 / kPieces;
-    return C.buf + (j / kRays) * 64 + (j % kRays) * kPieces;
-}
-
-// One node visit of every lane in `mask` (= ballot(want)), 64-byte records.  Called by all 64 lanes.
-template <int kSpill>
-__device__ __forceinline__ void sahq_node_step_coop(const RenderParams &P, const CoopView &C, int lane, bool want, unsigned long long mask,
-                                                    SahWalk &W, v3 o, const SahStack &S, uint32_t &n_box)
-{
-    const int n_rays = pt_popc(mask);
-    const int idx = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    if (want) C.slot[idx] = W.pair | 4u;
-    wave_lds_fence();
-    coop_issue<4>(C, reinterpret_cast<const char *>(P.nodes), lane, 0, n_rays);
-    if (want) sah_stack_reserve<kSpill>(S, W, 3);           // (while the records are on their way)
-    coop_wait();
-    if (want) {
-        const float4 *rec = coop_record<4>(C, idx);
-        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], lk = rec[3];
-        sahq_node_eval<kSpill>(W, o, S, q0, q1, q2, lk, n_box);
-    }
-}
-
-// The pending leaf (up to four of its triangles: the builder's leaves; longer ones take another trip) of every lane in
-// `mask`, in rounds of 20 leaves.  Same tests in the same order per lane as sahw_tri_step.  Called by all 64 lanes.
-template <int kSpill>
-__device__ __forceinline__ void sahw_tri_step_coop(const RenderParams &P, const CoopView &C, int lane, bool want, unsigned long long mask,
-                                                   SahWalk &W, v3 o, v3 d, float tmin, const SahStack &S, uint32_t &n_tri)
-{
-    constexpr int kLeaf = 4, kPieces = 3 * kLeaf, kRound = (kCoopBuf / 64) * (64 / kPieces);
-    const int n_rays = pt_popc(mask);
-    const int idx = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    const uint32_t n = want ? (W.n0 < (uint32_t)kLeaf ? W.n0 : (uint32_t)kLeaf) : 0u;
-    if (want) C.slot[idx] = W.k0 | (3u * n);
-    wave_lds_fence();
-    for (int first = 0; first < n_rays; first += kRound) {       // wave-uniform
-        const int count = n_rays - first < kRound ? n_rays - first : kRound;
-        coop_issue<kPieces>(C, reinterpret_cast<const char *>(P.tris), lane, first, count);
-        coop_wait();
-        const int j = idx - first;
-        if (want && j >= 0 && j < kRound) {
-            const float4 *rec = coop_record<kPieces>(C, j);
-#pragma unroll
-            for (uint32_t t = 0; t < (uint32_t)kLeaf; t++) {
-                if (t < n) {
-                    const float4 ta = rec[3 * t], tb = rec[3 * t + 1], tc = rec[3 * t + 2];
-                    float tt, u, v;
-                    const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d, tt, u, v);
-                    const uint32_t rank = __float_as_uint(tc.y);
-                    if (ok & (tt > tmin) & ((tt < W.tbest) | ((tt == W.tbest) & (rank < W.best_rank)))) {
-                        W.tbest = tt; W.best_rank = rank; W.best_off = W.k0 + t * (uint32_t)sizeof(TriIsect);
-                    }
-                }
-            }
-        }
-        wave_lds_fence();                                    // the round's reads are issued before the next round's fetch
-    }
-    if (want) {
-        n_tri += n;
-        W.k0 += n * (uint32_t)sizeof(TriIsect); W.n0 -= n;
-        if ((W.n0 == 0) & (W.pair == kNoPair)) sahw_pop<kSpill>(W, S);
-    }
 }
 
 // The finished walk's hit record.  want_uv: the scene has textures (the only reader of the barycentrics, pt_shade.h).

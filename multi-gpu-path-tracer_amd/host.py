@@ -447,6 +447,15 @@ class DevicePathTracer:
                                                  capi.np_ptr(f), len(o)))
         return t, f
 
+    def katWalkCost(self, origins: np.ndarray, dirs: np.ndarray):
+        """Box and triangle tests per ray of the walk katClosestHit runs (diagnostic)."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        nb = np.zeros(len(o), np.uint32)
+        nt = np.zeros(len(o), np.uint32)
+        capi.check(capi.lib().pt_kat_walk_cost(self._h, capi.np_ptr(o), capi.np_ptr(d), capi.np_ptr(nb), capi.np_ptr(nt), len(o)))
+        return nb, nt
+
 
 def _stream_ptr(stream):
     if stream is None:

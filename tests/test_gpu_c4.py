@@ -144,7 +144,7 @@ def test_c4_scale_closest_hit_gate(pt, ob, terrain, gpu_device):
     ref_tr = pt.DevicePathTracer(0, 1, 1, (8, 8), terrain, fb, pt.CameraConfig(*TERRAIN_CAMERA), bvhMode=0)
     t_ref, f_ref = np.empty_like(t_sah), np.empty_like(f_sah)
     t0 = time.perf_counter()
-    chunk = 50_000                                                 # a launch of the unpruned walk stays in the seconds
+    chunk = 200_000                                                # a launch of the unpruned walk stays in the seconds
     for a in range(0, n, chunk):
         t_ref[a:a + chunk], f_ref[a:a + chunk] = ref_tr.katClosestHit(org[a:a + chunk], dirs[a:a + chunk])
     t_ref_s = time.perf_counter() - t0

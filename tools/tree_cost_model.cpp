@@ -33,8 +33,8 @@ static V norm(V a) { double l = std::sqrt(dot(a, a)); return (1.0 / l) * a; }
 struct Tri { V v0, e1, e2, n; int mat; };
 struct Ray { V o, d; };
 
-struct Child { float b[6]; int node; uint32_t first, count; };      // node >= 0: inner; else leaf [first, first + count)
-struct WNode { std::vector<Child> ch; };
+struct Child { float b[6]; int node; uint32_t first, count; uint8_t q[6]; };      // node >= 0: inner; else leaf [first, first + count)
+struct WNode { std::vector<Child> ch; float org[3] = {0, 0, 0}, unit[3] = {0, 0, 0}; };
 
 struct Tree {
     std::vector<WNode> nodes;
@@ -95,13 +95,16 @@ static void quantise(Tree &T)
                 while (bl > 0 && !(std::fmaf((float)bl, unit, mn[a]) <= c.b[2 * a])) bl--;
                 while (bh < 255 && !(std::fmaf((float)bh, unit, mn[a]) >= c.b[2 * a + 1])) bh++;
                 c.b[2 * a] = std::fmaf((float)bl, unit, mn[a]); c.b[2 * a + 1] = std::fmaf((float)bh, unit, mn[a]);
+                c.q[2 * a] = (uint8_t)bl; c.q[2 * a + 1] = (uint8_t)bh;
             }
+            n.org[a] = mn[a]; n.unit[a] = unit;
         }
     }
 }
 
 struct Cost { double visits = 0, leaves = 0, tris = 0, req = 0, stale = 0, maxsp = 0, boxes = 0; };
-struct Layout { const char *name; int node_bytes; int tri_bytes; bool packed_leaf; bool prune_pop; bool full_sort; };
+static std::vector<float> g_steps;      // per segment: node visits + leaves (the chain of dependent steps)
+struct Layout { const char *name; int node_bytes; int tri_bytes; bool packed_leaf; bool prune_pop; bool full_sort; int arith = 0; /* 0 double, 1 the kernel's float decode + slab, 2 the folded float form */ };
 
 static bool mt(const Tri &t, const Ray &r, double tmin, double tmax, double &tout)
 {
@@ -138,7 +141,22 @@ static int walk(const Tree &T, const std::vector<Tri> &tris, const Ray &r, const
             C.req += L.node_bytes / 16;
             C.boxes += (double)n.ch.size();
             Ent hit[16]; int nh = 0;
+            const float fo[3] = {(float)r.o.x, (float)r.o.y, (float)r.o.z}, fi[3] = {1.0f / (float)r.d.x, 1.0f / (float)r.d.y, 1.0f / (float)r.d.z};
+            float fa[3], fb[3];
+            for (int a = 0; a < 3; a++) { fa[a] = n.unit[a] * fi[a]; fb[a] = (n.org[a] - fo[a]) * fi[a]; }
             for (const Child &c : n.ch) {
+                if (L.arith != 0) {
+                    float t[6];
+                    for (int k = 0; k < 6; k++) {
+                        const int a = k / 2;
+                        if (L.arith == 1) t[k] = (std::fmaf((float)c.q[k], n.unit[a], n.org[a]) - fo[a]) * fi[a];
+                        else t[k] = std::fmaf((float)c.q[k], fa[a], fb[a]);
+                    }
+                    const float tn = std::fmax(std::fmax(std::fmin(t[0], t[1]), std::fmin(t[2], t[3])), std::fmin(t[4], t[5]));
+                    const float tf = std::fmin(std::fmin(std::fmax(t[0], t[1]), std::fmax(t[2], t[3])), std::fmax(t[4], t[5]));
+                    if (tf >= std::fmax(tn, 0.0f) && tn <= (float)tbest) hit[nh++] = Ent{c.node, c.first, c.count, tn};
+                    continue;
+                }
                 const double t1 = (c.b[0] - r.o.x) * ix, t2 = (c.b[1] - r.o.x) * ix, t3 = (c.b[2] - r.o.y) * iy, t4 = (c.b[3] - r.o.y) * iy;
                 const double t5 = (c.b[4] - r.o.z) * iz, t6 = (c.b[5] - r.o.z) * iz;
                 const double tn = std::fmax(std::fmax(std::fmin(t1, t2), std::fmin(t3, t4)), std::fmin(t5, t6));
@@ -199,6 +217,8 @@ int main(int argc, char **argv)
     std::vector<Variant> variants = {
         {4, 4, false, {"K4 leaf4 fp32 128B / tri 48B (sahw)", 112, 48, false, false, false}},
         {4, 4, true,  {"K4 leaf4 q8   64B / tri 48B (sahq = r03)", 64, 48, false, false, false}},
+        {4, 4, true,  {"K4 leaf4 q8   64B, float decode + slab (kernel)", 64, 48, false, false, false, 1}},
+        {4, 4, true,  {"K4 leaf4 q8   64B, folded float slab", 64, 48, false, false, false, 2}},
         {4, 4, true,  {"K4 leaf4 q8   48B / tri 48B", 48, 48, false, false, false}},
         {4, 4, true,  {"K4 leaf4 q8   48B / tri 40B packed", 48, 40, true, false, false}},
         {4, 4, true,  {"K4 leaf4 q8   48B / tri 36B packed", 48, 36, true, false, false}},
@@ -275,10 +295,13 @@ int main(int argc, char **argv)
     for (const Variant &vr : variants) {
         prepare(vr.K, vr.max_leaf, vr.quant);
         Cost c;
-        for (const Ray &r : segs) { double t; (void)walk(T, tris, r, vr.L, c, t); }
+        g_steps.clear();
+        for (const Ray &r : segs) { double t; const double before = c.visits + c.leaves; (void)walk(T, tris, r, vr.L, c, t); g_steps.push_back((float)(c.visits + c.leaves - before)); }
+        std::sort(g_steps.begin(), g_steps.end());
         const double s = (double)segs.size();
         printf("%-52s %8zu %8.2f %8.2f %8.2f %8.2f %8.2f %9.1f %6.0f\n", vr.L.name, T.nodes.size(), c.visits / s, c.boxes / s, c.leaves / s, c.tris / s, c.req / s,
                (double)T.nodes.size() * vr.L.node_bytes / 1e6, c.maxsp);
+        printf("%-52s steps per segment: p50 %.0f p99 %.0f p99.9 %.0f max %.0f\n", "", g_steps[g_steps.size() / 2], g_steps[g_steps.size() * 99 / 100], g_steps[g_steps.size() * 999 / 1000], g_steps.back());
         fflush(stdout);
     }
     pt_scene_free(hs);
