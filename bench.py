@@ -66,7 +66,7 @@ def kernel_build_id():
     return h.hexdigest()[:16]
 
 
-def matching_profile(config, workload, build_id):
+def matching_profile(config, workload, build_id, frames_in_flight=None):
     """The committed rocprofv3 PMC summary (profiles/*_<config>_pmc_summary.json; FETCH_SIZE / WRITE_SIZE / SQ
     counters collected in separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes) of this exact
     workload string (scene, frame size, spp, depth, tree).  Returns (summary dict, path, same_build) or
@@ -83,6 +83,10 @@ def matching_profile(config, workload, build_id):
             line = d["bench_line_under_kernel_trace"]
             if line["config"]["workload"] != workload:
                 continue
+            # a launch that shares the device with another one is a different launch (issue priority off, another split rule):
+            # its per-launch counts only describe runs with the same number of frames in flight
+            if frames_in_flight is not None and int(line.get("frames_in_flight", 1)) != int(frames_in_flight):
+                continue
             same = line.get("kernel_build_id") == build_id
             if same or best[0] is None or not best[2]:
                 best = (d, os.path.relpath(path, ROOT), same)
@@ -91,12 +95,40 @@ def matching_profile(config, workload, build_id):
     return best
 
 
-def roofline_block(config, workload, cnt, pixels, kernel_ms, launches, kernel_name, device_ms_per_launch=None):
+def op_table():
+    """profiles/*_op_table.json (tools/op_table.py): VALU instructions of one slab test, one Moller-Trumbore test, one light-pdf
+    test, one scattering bounce and one path start with all lanes live, counted in the ISA of this build's own functions."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_op_table.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return json.load(f), os.path.relpath(files[-1], ROOT)
+
+
+def algorithmic_ops(cnt, launches):
+    """Per launch: what the reference's source asks for, in instructions of this build with every lane live -- the tests the
+    kernel counted times the table's per-test instructions, a scattering bounce for every segment that is not a path's last,
+    a path start per path.  Votes, merges, the walks' address arithmetic, the SAH forms' decode / sort / push and idle lanes
+    are NOT in it: executed - algorithmic is the overhead."""
+    t, path = op_table()
+    if t is None:
+        return None
+    n = max(launches, 1)
+    scattering = max(cnt["segments"] - cnt["paths"], 0)
+    ops = (cnt["box_tests"] * t["per_box_test"] + cnt["tri_tests"] * t["per_triangle_test"] + cnt["light_tests"] * t["per_light_test"]
+           + scattering * t["per_scattering_segment"] + cnt["paths"] * t["per_path_start"]) / n
+    return {"ops_per_launch": ops, "ops_per_segment": ops * n / max(cnt["segments"], 1), "table": path,
+            "per_test": {k: t[k] for k in ("per_box_test", "per_triangle_test", "per_light_test", "per_scattering_segment", "per_path_start")},
+            "table_build_id": t.get("kernel_build_id")}
+
+
+def roofline_block(config, workload, cnt, pixels, kernel_ms, launches, kernel_name, device_ms_per_launch=None, frames_in_flight=1):
     """The bound that binds, with the time measured in THIS run (HIP events on the launch stream, pt_kernel_time_read).
     device_ms_per_launch: frames in flight -- the launches overlap, so the time that goes with one launch's counts is the
     device time all timed launches took together (first start to last end, HIP events on their streams) / their number."""
     build_id = kernel_build_id()
-    prof, path, same_build = matching_profile(config, workload, build_id)
+    prof, path, same_build = matching_profile(config, workload, build_id, frames_in_flight)
     per_launch_s = (device_ms_per_launch if device_ms_per_launch is not None else kernel_ms / max(launches, 1)) * 1e-3
     alg = algorithmic_bytes(cnt, pixels) / max(launches, 1)
     hbm_bound = config == "c4"         # the only scene (1 GB) that does not live in the scalar cache / L1 / L2
@@ -105,8 +137,11 @@ def roofline_block(config, workload, cnt, pixels, kernel_ms, launches, kernel_na
         if "hbm_bytes_per_launch" in prof:
             traffic = float(prof["hbm_bytes_per_launch"]["total"])
         c = prof.get("counters", {})
-        if "SQ_THREAD_CYCLES_VALU" in c:
-            lane_instr = float(c["SQ_THREAD_CYCLES_VALU"])     # VALU lane-instructions of one launch
+        if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c and "SQ_INSTS_VALU" in c:
+            # executed VALU lane-instructions of one launch = wave-instructions x 64 x lane utilisation, the convention of
+            # tools/make_profile_summary.py (so the line and its profile agree to the digit)
+            util = float(c["SQ_THREAD_CYCLES_VALU"]) / (float(c["SQ_ACTIVE_INST_VALU"]) * 64.0)
+            lane_instr = float(c["SQ_INSTS_VALU"]) * 64.0 * util
     out = {"bound": "hbm" if hbm_bound else "valu-issue"}
     if hbm_bound:
         achieved = traffic / per_launch_s / 1e9 if (traffic and per_launch_s > 0) else None
@@ -137,6 +172,17 @@ def roofline_block(config, workload, cnt, pixels, kernel_ms, launches, kernel_na
     })
     if hbm_bound and lane_instr and same_build and per_launch_s > 0:
         out["valu_issue_frac"] = lane_instr / per_launch_s / VALU_PEAK_LANE_INSTR_S
+    alg_ops = algorithmic_ops(cnt, launches)
+    if alg_ops is not None and per_launch_s > 0:
+        # the ALGORITHMIC numerator (SURVEY 8d asks for algorithmic work per unit): a kernel that executes
+        # more instructions for the same segments raises `frac` and lowers nothing here
+        out["algorithmic_ops_per_launch"] = alg_ops["ops_per_launch"]
+        out["algorithmic_ops_per_segment"] = alg_ops["ops_per_segment"]
+        out["algorithmic_frac"] = alg_ops["ops_per_launch"] / per_launch_s / VALU_PEAK_LANE_INSTR_S
+        out["algorithmic_source"] = ("%s (VALU instructions per test with all lanes live, from the ISA of this build's own functions: %s) x the "
+                                     "kernel's exact counters; over the same time and peak as frac" % (alg_ops["table"], alg_ops["per_test"]))
+        if lane_instr and same_build:
+            out["executed_over_algorithmic"] = lane_instr / alg_ops["ops_per_launch"]
     return out
 
 
@@ -229,6 +275,68 @@ ROOFLINE_NOTES = {
 ROOFLINE_NOTES["c1"] = ROOFLINE_NOTES["c5"] = ROOFLINE_NOTES["c2"]
 
 
+def native_host_leg(args):
+    """bench.py --host native: the reference-shaped host (RenderManager.h:76-112: ONE process, a StreamThread per GPU and
+    stream; here csrc/host/*.h -> pt_render) as a child process, its own JSON line relayed with the keys of the Python leg.
+    The frame = RenderManager::renderFrame incl. pt_gather_frame (RCCL ncclSend / ncclRecv to GPU 0, or peer copies) and the
+    copy to the host; counters are the engines' own."""
+    import subprocess
+    kind, W, H, spp, depth, desc = CONFIGS[args.config]
+    if args.width or args.height:
+        W, H = args.width or W, args.height or H
+    if args.spp:
+        spp = args.spp
+    exe = os.path.join(ROOT, "multi-gpu-path-tracer_amd", "pt_render")
+    if not os.path.exists(exe):
+        raise SystemExit("bench.py --host native needs %s (make -C multi-gpu-path-tracer_amd/csrc all)" % exe)
+    if kind == "terrain":
+        raise SystemExit("bench.py --host native: the terrain is generated in the library, pt_render loads files (c1 / c2 / c3 / c5)")
+    model = os.path.join(ROOT, "models", "cornell_box.glb" if kind == "box" else "cornell_duck.glb")
+    cam = BOX_CAMERA if kind == "box" else DUCK_CAMERA
+    bvh = args.bvh or "reference"
+    fif = args.frames_in_flight or (4 if args.gpus >= 8 else 3 if args.gpus > 1 else 2)
+    cmd = [exe, "bench", model, "--width", str(W), "--height", str(H), "--spp", str(spp), "--depth", str(depth),
+           "--gpus", str(args.gpus), "--frames", str(args.steps), "--warmup", str(args.warmup), "--frames-in-flight", str(fif),
+           "--lookfrom", "%g,%g,%g" % cam[0], "--front", "%g,%g,%g" % cam[1], "--json", "--out", ""]
+    if kind == "box":
+        cmd.append("--cornell")
+    if bvh == "sah":
+        cmd += ["--bvh", "sah"]
+    if args.rehearse:
+        cmd.append("--same-device")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+    sys.stderr.write(r.stderr)
+    line = None
+    for l in r.stdout.splitlines():
+        if l.startswith("{"):
+            line = json.loads(l)
+    if r.returncode != 0 or line is None:
+        sys.stderr.write(r.stdout)
+        return r.returncode or 1
+    seg = line["segments"]
+    out = {
+        "metric": "ray-segments/s", "value": seg / (line["ms_total"] * 1e-3), "unit": "ray-segments/s",
+        "n_gpus": args.gpus, "ranks": line["devices"], "backend": line["gather_transport"] or "none",
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": line["ms_total"] / max(args.steps, 1),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "host": "native (pt_render: one process, %d worker thread(s), csrc/host/RenderManager.h)" % line["workers"],
+        "config": {"workload": "%s [bvh=%s]" % (desc, bvh), "scene": kind, "width": W, "height": H, "spp": spp, "bounces": depth,
+                   "parity": PARITY_NOTE,
+                   "parallelism": "one task per (GPU, stream) (%s), scene replicated, pt_gather_frame to GPU 0 + one copy to the host, %d frame%s in flight per GPU"
+                                  % (line["algorithm"], line["frames_in_flight"], "" if line["frames_in_flight"] == 1 else "s")},
+        "frames_in_flight": line["frames_in_flight"],
+        "frame_delivery": "host-visible: the shared host Framebuffer holds every completed frame (RenderManager::renderFrame)",
+        "segments_per_frame": seg // max(args.steps, 1),
+        "segments_per_path": seg / max(line["paths"], 1),
+        "tests_per_segment": {"box_tests": line["box_tests"] / max(seg, 1), "tri_tests": line["tri_tests"] / max(seg, 1), "light_tests": line["light_tests"] / max(seg, 1)},
+        "kernel_build_id": kernel_build_id(),
+    }
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,7 +349,14 @@ def main():
                          "every frame from the previous frame's per-band costs, longest first (default for c5, whose "
                          "BASELINE config names a dynamic load-balancer; fsfl otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-visible", action="store_true", help="skip the extra frames timed with the D2H copy of the frame")
+    ap.add_argument("--no-host-visible", action="store_true", help="skip the extra leg that times one frame at a time (a frame's latency)")
+    ap.add_argument("--device-frames", action="store_true",
+                    help="diagnostic: leave the frames on the device (no copy to the host inside the timed region): the kernel-only "
+                         "figure of rounds 1-3; the default delivers every frame host-visible, as SURVEY 8(d) defines a frame")
+    ap.add_argument("--host", default="python", choices=["python", "native"],
+                    help="python: one process per GPU over torch.distributed / RCCL (the default, what the driver launches); native: "
+                         "the C++ host mirror (pt_render: ONE process, a worker thread per GPU and stream, pt_gather_frame over RCCL "
+                         "or peer copies), started as a child process, its line relayed with the same keys")
     ap.add_argument("--tile-schedule", type=int, default=1, choices=[0, 1],
                     help="0: tiles in raster order; 1: ordered by their cost in the previous frame (pt_set_tile_schedule)")
     ap.add_argument("--cpu-rows", type=int, default=360)
@@ -273,6 +388,9 @@ def main():
     # it (an eighth of C2 with 4 frames in flight: 9.9 ms per frame on 4 queues, 7.8 on 8).  Read when the runtime
     # initialises: set before torch is imported, and handed on to the ranks this process may start.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+    if args.host == "native":
+        raise SystemExit(native_host_leg(args))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Started without a launcher (`python bench.py --gpus N`): this process becomes the launcher.  It has not
@@ -340,9 +458,10 @@ def main():
     # framebuffer on its own stream: the next frame's waves take the wave slots the current frame's last chains leave empty
     # (one GPU, C2: 59.6 -> 55.6 ms per frame; an eighth of C2: 13.7 -> 7.8 ms; profiles/r03_frames_in_flight.json).  The
     # timed region starts and ends with an empty pipeline.  The cost-fed dealers keep one frame in flight.
-    fif = args.frames_in_flight or ((4 if world >= 8 else 3 if world > 1 else 2) if (world == 1 or algo == "fsfl") else 1)
+    # (the cost-fed dealers pipeline too since round 4: every frame in flight carries its own band assignment)
+    fif = args.frames_in_flight or (4 if world >= 8 else 3 if world > 1 else 2)
     mgr = pt.RenderManager(cfg, scene, cam, device_idx=local_rank, band_rows=args.band_rows,
-                           bvh_mode=1 if bvh == "sah" else 0, frames_in_flight=fif)
+                           bvh_mode=1 if bvh == "sah" else 0, frames_in_flight=fif, host_frames=not args.device_frames)
     fif = mgr.frames_in_flight
     upload_s = time.perf_counter() - t_up
     mgr.tracer.setTileSchedule(args.tile_schedule)
@@ -424,28 +543,23 @@ def main():
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
         kernel_ms = float(kmax.item())
 
-    # SURVEY 8(d) defines the frame as "incl. gather to host-visible RGB": the boundary hands over DEVICE buffers
-    # (`value` above), so the host-visible variant -- every frame followed by the D2H copy of RGB + YUV into pinned
-    # host memory on rank 0 -- is timed separately and reported beside it.
-    host_visible_ms = None
+    # SURVEY 8(d) defines the frame as "incl. gather to host-visible RGB" (RenderManager.h:410-431 ends on a barrier and the
+    # host reads the managed framebuffer, Framebuffer.h:27-35).  The timed region above IS that frame since round 4: every
+    # completed frame is copied, RGB + YUV, into pinned host memory on a stream of its own under the rendering of the next
+    # (RenderManager(host_frames=True)), and the region ends when the last copy has landed.  What it cannot show is a single
+    # frame's LATENCY: this leg renders one frame at a time, each delivered to the host before the next starts.
+    latency_ms = None
     if not args.no_host_visible:
-        fb = mgr.getFramebuffer()
-        pin_rgb = torch.empty(fb.rgb.numel(), dtype=torch.uint8).pin_memory() if rank == 0 else None
-        pin_yuv = torch.empty(fb.yuv.numel(), dtype=torch.uint8).pin_memory() if rank == 0 else None
         n_hv = max(1, min(args.steps, 5))
-        if rank == 0:                                  # first touch of the pinned pages is not part of a frame
-            pin_rgb.copy_(fb.rgb); pin_yuv.copy_(fb.yuv)
         sync_all()
         t0 = time.perf_counter()
         for _ in range(n_hv):
             mgr.renderFrame()
-            mgr.flush()                                # one frame at a time here: this is a frame's LATENCY, whatever is in flight above
-            fb = mgr.getFramebuffer()
-            if rank == 0:
-                pin_rgb.copy_(fb.rgb, non_blocking=True); pin_yuv.copy_(fb.yuv, non_blocking=True)
-                torch.cuda.synchronize()               # the frame is host-visible here
+            mgr.flush()                                # one frame at a time: rendered, exchanged, copied (flush waits for the copy)
+            if rank == 0 and not args.device_frames:
+                assert mgr.hostFrame() is not None
         sync_all()
-        host_visible_ms = (time.perf_counter() - t0) * 1e3 / n_hv
+        latency_ms = (time.perf_counter() - t0) * 1e3 / n_hv
 
     if rank == 0:
         if args.ppm:
@@ -465,6 +579,9 @@ def main():
                        "parallelism": "row-bands x%d (band_rows=%d, dealer=%s), scene replicated, true-size sends to rank 0, %d frame%s in flight per GPU"
                                       % (world, args.band_rows, algo if world > 1 else "n/a", fif, "" if fif == 1 else "s")},
             "frames_in_flight": fif,
+            "frame_delivery": ("device framebuffer only (diagnostic)" if args.device_frames else
+                               "host-visible: RGB + YUV of every frame copied into pinned host memory on rank 0, overlapped with the next frame's rendering; "
+                               "the timed region ends when the last copy has landed (SURVEY 8d's frame)"),
             "segments_per_frame": total["segments"] // args.steps,
             "scene_upload_s": upload_s,
             "segments_per_path": total["segments"] / max(total["paths"], 1),
@@ -475,13 +592,15 @@ def main():
             # whole-frame launch and do not apply to a 1/N share, so `achieved` stays null there)
             "roofline": roofline_block(args.config, desc if world == 1 else desc + " [1/%d shares]" % world, total,
                                        W * H * args.steps, kernel_ms, launches, mgr.tracer.kernelName(),
-                                       device_ms_per_launch if fif > 1 else None),
+                                       device_ms_per_launch if fif > 1 else None, fif),
         }
-        if host_visible_ms is not None:
-            out["ms_per_step_host_visible"] = host_visible_ms      # one frame at a time, each copied to the host: a frame's latency
+        if latency_ms is not None:
+            out["ms_per_frame_latency"] = latency_ms               # one frame at a time, each delivered to the host before the next starts
+            out["ms_per_step_host_visible"] = latency_ms           # (the key of rounds 2-3 for the same quantity)
         if fif > 1:
-            out["frames_in_flight_note"] = ("ms_per_step = the timed region (K frames launched, rendered, exchanged; pipeline empty at both "
-                                            "ends) / K with %d frames queued per GPU; ms_per_step_host_visible renders one frame at a time" % fif)
+            out["frames_in_flight_note"] = ("ms_per_step = the timed region (K frames launched, rendered, exchanged, delivered to the host; pipeline "
+                                            "empty at both ends) / K with %d frames queued per GPU: a frame RATE; ms_per_frame_latency renders one "
+                                            "frame at a time, each host-visible before the next starts: a frame's LATENCY" % fif)
             out["roofline"]["kernel_ms_note"] = ("launches overlap (%d frames in flight): kernel_ms_avg is a launch's own duration, device_ms_per_launch = "
                                                  "(last end - first start of the timed launches, HIP events on their streams) / launches is what one "
                                                  "launch's counts are divided by" % fif)

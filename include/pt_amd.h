@@ -102,6 +102,11 @@ typedef void *pt_stream;                     /* hipStream_t; NULL = the null str
 /* ------------------------------------------------------------------------- errors -- */
 PT_API const char *pt_last_error_string(void);
 PT_API const char *pt_version(void);
+/* Hardware queues the HIP runtime maps this process's streams onto = how many launches on different streams can overlap
+ * (frames in flight; RenderManager.h:410-431 has no counterpart: the reference's renderFrame ends on a barrier).  The
+ * library sets GPU_MAX_HW_QUEUES=8 when it is loaded unless the host has set it, and returns what the variable said then; a
+ * process that initialised the HIP runtime before loading the library must export the variable itself. */
+PT_API int pt_hw_queue_count(void);
 
 /* --------------------------------------------------------- per-GPU engine (device) -- */
 /* DevicePathTracer ctor, DevicePathTracer.h:169-192 (cudaSetDevice part). */
@@ -208,6 +213,9 @@ PT_API pt_status pt_render_band_list_async(pt_device *dev, int band_rows, const 
  * whichever GPU renders the band.  Waits for that launch.  *n_bands = 0 when nothing was recorded (tile schedule off or
  * a launch of fewer than 256 tiles).                                                                        */
 PT_API pt_status pt_band_costs_read(pt_device *dev, uint64_t *costs, int max_bands, int *n_bands);
+/* ... of the latest row-band launch enqueued on `stream`: a host that keeps several frames in flight, each on its own
+ * stream, reads the costs of the frame it has just completed (scheduling.py's cost-fed dealers under frames in flight). */
+PT_API pt_status pt_band_costs_read_on(pt_device *dev, pt_stream stream, uint64_t *costs, int max_bands, int *n_bands);
 /* synchronizeStream(cudaStream_t), DevicePathTracer.h:222-226. */
 PT_API pt_status pt_stream_sync(pt_device *dev, pt_stream stream);
 /* waitForRenderTask(), DevicePathTracer.h:216-220. */

@@ -4,6 +4,13 @@ Framebuffer surface.  All compute lives in libptamd.so (hand-written HIP for gfx
 C ABI in include/pt_amd.h); this package is the Python host mirror used by bench.py and
 the tests.  Import it with importlib.import_module("multi-gpu-path-tracer_amd").
 """
+import os as _os
+
+# Frames in flight want one hardware queue per frame (include/pt_amd.h pt_hw_queue_count): the HIP runtime reads this once,
+# at its first call -- importing this package before anything touches the GPU is early enough (libptamd.so sets the same
+# default when it is loaded, which for this package is at the first C-ABI call).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from . import _capi as capi
 from .host import (CameraConfig, DevicePathTracer, Framebuffer, HostScene, RendererConfig, RenderTask,
                    Resolution, SceneLoader, FSFL, DSFL, DSDL, host_bvh_build, host_sah_build, make_terrain_scene,

@@ -147,6 +147,8 @@ _PROTOS = {
     "pt_kat_exhaustive": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint64, _vp, _vp, C.c_int]),
     "pt_kat_closest_hit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_size_t]),
     "pt_kat_walk_cost": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_size_t]),
+    "pt_band_costs_read_on": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "pt_hw_queue_count": (C.c_int, []),
     "pt_scene_load_glb": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "pt_scene_load_obj": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "pt_scene_create": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(Texture), C.c_size_t, C.POINTER(_vp)]),

@@ -78,12 +78,23 @@ public:
         queueActive_.store(config_.algorithmType == DQRB);
         // frames in flight: FSFL only (the adaptive policies time a task that has the device to itself)
         fif_ = config_.algorithmType == FSFL ? std::max(1u, config_.framesInFlight) : 1u;
+        // launches only overlap while each has a hardware queue of its own (include/pt_amd.h pt_hw_queue_count): more frames
+        // in flight than queues are slower than fewer, so the pipeline is no deeper than the queues the process has
+        if (fif_ > (unsigned)std::max(1, pt_hw_queue_count())) {
+            std::cerr << "warning: framesInFlight " << fif_ << " capped at the " << pt_hw_queue_count()
+                      << " hardware queues of this process (GPU_MAX_HW_QUEUES)" << std::endl;
+            fif_ = (unsigned)std::max(1, pt_hw_queue_count());
+        }
         frameIndex_.store(0); firstValid_.store(0); draining_.store(false); inflight_ = 0;
         for (unsigned i = 0; i < config_.gpuNumber; i++) {
             devicePathTracers_.push_back(std::make_shared<DevicePathTracer>(
-                (int)i, config_.samplesPerPixel, config_.recursionDepth, config_.threadBlockSize, hScene_, framebuffer_,
+                config_.allOnDevice0 ? 0 : (int)i, config_.samplesPerPixel, config_.recursionDepth, config_.threadBlockSize, hScene_, framebuffer_,
                 cameraConfig_));
             if (fif_ > 1) devicePathTracers_.back()->setFramesInFlight(fif_);
+            // DQRB launches 64-128 bands per frame, each its own task geometry: a cost-ordered tile schedule per band would be
+            // made, sorted and evicted every launch (the library caches 16) and never reused -- and a band has fewer tiles
+            // than the device has wave slots, so their order does not matter.  Bands render in raster order.
+            if (config_.algorithmType == DQRB) devicePathTracers_.back()->setTileSchedule(0);
         }
         // The gather group is made BEFORE any worker thread exists: nothing is parked on the barrier if it fails.  It
         // only fails on a HIP error: without a usable librccl (or when ncclCommInitAll refuses) the group moves the same
@@ -199,6 +210,8 @@ public:
             setup();
             return;
         }
+        if (queueActive_.load() != (config_.algorithmType == DQRB))      // (see setup(): no per-band tile schedules under DQRB)
+            for (auto &dpt : devicePathTracers_) dpt->setTileSchedule(config_.algorithmType == DQRB ? 0 : 1);
         queueActive_.store(config_.algorithmType == DQRB);       // workers read it after the frame's first barrier
         if (resChanged) {
             for (auto &dpt : devicePathTracers_) dpt->setFramebuffer(framebuffer_);

@@ -46,6 +46,10 @@ struct RendererConfig {
     // GPU, each in its own device framebuffer on its own stream.  With F > 1 renderFrame() launches frame i and hands out
     // frame i - F + 1 (RenderManager::flush() completes the rest); FSFL only -- the adaptive policies time a task alone.
     unsigned int framesInFlight = 1;
+    // Rehearsal on a box with ONE GPU: engine i still gets its own pt_device, streams, framebuffers and share of the frame,
+    // but all of them on device 0 (the gather then runs its peer-copy transport within the device).  Checks the N-engine
+    // path, not its speed.
+    bool allOnDevice0 = false;
 };
 
 struct CameraConfig {

@@ -1,4 +1,6 @@
 // pt_common.cpp -- error reporting and the host-side task generators of the C ABI.
+#include <stdlib.h>
+
 #include "pt_internal.h"
 
 #include <new>
@@ -38,6 +40,24 @@ extern "C" {
 
 const char *pt_last_error_string(void) { return g_error.c_str(); }
 const char *pt_version(void) { return "ptamd 0.1 (gfx950)"; }
+
+// Hardware queues.  Launches on different streams only overlap on the device while each stream has a hardware queue of its
+// own; the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES queues (4 unless the variable says otherwise) and reads
+// the variable ONCE, when it initialises.  Frames in flight (RendererConfig::framesInFlight, scheduling.py) want one queue per
+// frame: a fourth launch that shares a queue waits behind another stream's persistent kernel (an eighth of C2 with four frames
+// in flight: 9.9 ms per frame on 4 queues, 7.8 on 8).  So the library asks for 8 when it is LOADED, unless the host has set the
+// variable itself -- for a host that links libptamd.so that is before main(), before any HIP call -- and tells what it found:
+// the hosts cap their frames in flight at pt_hw_queue_count().  (A process that initialised the HIP runtime BEFORE loading the
+// library, with the variable unset, runs on the runtime's 4 whatever is set afterwards: export GPU_MAX_HW_QUEUES there.)
+static int g_hw_queues = 4;
+__attribute__((constructor)) static void ptamd_on_load()
+{
+    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    const int v = e ? atoi(e) : 4;
+    g_hw_queues = v >= 1 ? v : 4;
+}
+int pt_hw_queue_count(void) { return g_hw_queues; }
 
 pt_status pt_host_bvh_build(const pt_triangle *tris, size_t n, pt_bvh_info *info, float *bounds6,
                             uint32_t *links4, int *tri_indices)

@@ -911,12 +911,15 @@ struct pt_device {
     uint64_t launches = 0;
     const char *last_kernel = "";  // what the latest render launch ran (pt_kernel_name_read)
     // latest row-band launch, for pt_band_costs_read: its schedule (null = no costs recorded) and geometry
-    uint64_t band_sched_id = 0;              // TileSchedule::id of the latest band launch's schedule (0 = none)
-    int band_tiles_x = 0, band_tiles_y = 0, band_rows_last = 0, band_local_rows = 0;
+    // The latest row-band launch of every stream (pt_band_costs_read / _on): its schedule (by id; 0 = no costs recorded) and
+    // geometry.  A host that keeps several frames in flight, each on its own stream, reads the costs of the frame it has just
+    // completed, not those of the newest launch.
+    struct BandLaunch { hipStream_t stream; uint64_t sched_id; int tiles_x, tiles_y, band_rows, local_rows; uint64_t stamp; };
+    std::vector<BandLaunch> band_launches;
+    uint64_t band_clock = 0;
     uint64_t last_sched_id = 0;              // TileSchedule::id of the latest launch's schedule (pt_split_tiles_read), and its stream
     uint64_t schedule_ids = 0;
     hipStream_t last_sched_stream = nullptr;
-    hipStream_t band_stream = nullptr;
 };
 
 // Traversal schedule for the uploaded tree.  The wave-uniform walks cost the UNION of the 64
@@ -1708,9 +1711,39 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
                                                   hipGetErrorString(e_) + ") at " + __FILE__ + ":" +       \
                                                   std::to_string(__LINE__) + " '" #call "'"));             \
     } while (0)
+    // bytes of overflow area this launch will want (persistent SAH kernel with a short LDS stack): known before the launch's
+    // first event is recorded, so that a (blocking) allocation never sits inside the timed span nor between queued launches
+    size_t spill_need = 0;
+    if (persistent && P.spill_blocks > 0) {
+        int per_cu = resident_per_cu(dev, (const void *)kern, lds);
+        if (dev->resident_cap > 0) per_cu = std::min(per_cu, dev->resident_cap);
+        const unsigned resident = std::min(blocks, (unsigned)(dev->cu_count * per_cu));
+        spill_need = (size_t)resident * dev::kWavesPerBlock * (size_t)P.spill_blocks * 64 * dev::kSpillBlock * sizeof(uint32_t);
+    }
     {
         std::lock_guard<std::mutex> lk(dev->mu);
-        if (!dev->free_events.empty()) { ev = dev->free_events.back(); dev->free_events.pop_back(); }
+        // Finished launches give their events, tile counter and overflow area back at EVERY launch (oldest first; launches
+        // finish roughly in the order they were enqueued): the pool stays as small as the number of launches in flight,
+        // whether or not anybody reads the timings (a streaming host never does), and with it the number of overflow areas
+        // (C4: 42 MB each).
+        {
+            size_t done = 0;
+            while (done < dev->pending.size() && hipEventQuery(dev->pending[done].second) == hipSuccess) {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, dev->pending[done].first, dev->pending[done].second) == hipSuccess) { dev->ms_total += (double)ms; dev->launches++; }
+                dev->free_events.push_back(dev->pending[done]);
+                done++;
+            }
+            if (done) dev->pending.erase(dev->pending.begin(), dev->pending.begin() + (long)done);
+            (void)hipGetLastError();      // hipEventQuery reports "not ready" through the error state
+        }
+        if (!dev->free_events.empty()) {
+            // prefer an entry whose overflow area is already big enough
+            size_t pick = dev->free_events.size() - 1;
+            for (size_t i = 0; i < dev->free_events.size(); i++) if (dev->free_events[i].spill_bytes >= spill_need && spill_need > 0) { pick = i; break; }
+            ev = dev->free_events[pick];
+            dev->free_events.erase(dev->free_events.begin() + (long)pick);
+        }
         else {
             hipError_t e1 = hipEventCreate(&ev.first), e2 = e1 == hipSuccess ? hipEventCreate(&ev.second) : e1;
             if (e2 == hipSuccess && dev->next_used % 256 == 0) {
@@ -1746,6 +1779,12 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
             if (split) { P.n_split = sched->n_split; P.split_parts = split_parts; }
         }
     }
+    if (spill_need > 0 && ev.spill_bytes < spill_need) {
+        // (first use of this entry, or a bigger launch than it has seen: the entry is ours alone, no launch is using its area)
+        (void)hipFree(ev.spill); ev.spill = nullptr; ev.spill_bytes = 0;
+        PT_HIP_LAUNCH(hipMalloc((void **)&ev.spill, spill_need));
+        ev.spill_bytes = spill_need;
+    }
     if (split && sched) {
         hipLaunchKernelGGL(dev::split_reset_kernel, dim3(1), dim3(256), 0, hs, sched->order, sched->cost, sched->n_split);
         PT_HIP_LAUNCH(hipGetLastError());
@@ -1758,16 +1797,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         int per_cu = resident_per_cu(dev, (const void *)kern, lds);
         if (dev->resident_cap > 0) per_cu = std::min(per_cu, dev->resident_cap);
         blocks = std::min(blocks, (unsigned)(dev->cu_count * per_cu));
-        if (P.spill_blocks > 0) {
-            // the launch's own overflow area for stacks deeper than their LDS part: one run of blocks per resident wave
-            const size_t need = (size_t)blocks * dev::kWavesPerBlock * (size_t)P.spill_blocks * 64 * dev::kSpillBlock * sizeof(uint32_t);
-            if (ev.spill_bytes < need) {
-                (void)hipFree(ev.spill); ev.spill = nullptr; ev.spill_bytes = 0;      // (recycled with its events: no launch is using it)
-                PT_HIP_LAUNCH(hipMalloc((void **)&ev.spill, need));
-                ev.spill_bytes = need;
-            }
-            P.stack_spill = ev.spill;
-        }
+        if (P.spill_blocks > 0) P.stack_spill = ev.spill;      // the launch's own overflow area (allocated above): one run of blocks per resident wave
     }
     // Frames in flight: launches of this device that are still running when this one is enqueued share its wave slots with
     // it (the pending launches' end events, newest first; launches finish roughly in the order they were enqueued).
@@ -1811,26 +1841,19 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
         dev->last_kernel = choice.name;
         dev->last_sched_id = sched ? sched->id : 0; dev->last_sched_stream = hs;
         if (P.band_rows > 0) {
-            dev->band_sched_id = sched ? sched->id : 0; dev->band_tiles_x = P.tiles_x; dev->band_tiles_y = P.tiles_y;
-            dev->band_rows_last = P.band_rows; dev->band_local_rows = P.task_h; dev->band_stream = hs;
+            pt_device::BandLaunch bl{hs, sched ? sched->id : 0, P.tiles_x, P.tiles_y, P.band_rows, P.task_h, ++dev->band_clock};
+            bool found = false;
+            for (auto &e : dev->band_launches) if (e.stream == hs) { e = bl; found = true; }
+            if (!found) {
+                if (dev->band_launches.size() >= 32) {         // (streams come and go: forget the one used longest ago)
+                    size_t old = 0;
+                    for (size_t i = 1; i < dev->band_launches.size(); i++) if (dev->band_launches[i].stamp < dev->band_launches[old].stamp) old = i;
+                    dev->band_launches.erase(dev->band_launches.begin() + (long)old);
+                }
+                dev->band_launches.push_back(bl);
+            }
         }
         dev->pending.push_back(ev);
-        // keep the event pool bounded when nobody reads the timings: fold finished launches in
-        if (dev->pending.size() > 64) {
-            size_t kept = 0;
-            for (auto &pr : dev->pending) {
-                float ms = 0.0f;
-                if (hipEventQuery(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-                    dev->ms_total += (double)ms;
-                    dev->launches++;
-                    dev->free_events.push_back(pr);
-                } else {
-                    dev->pending[kept++] = pr;
-                }
-            }
-            dev->pending.resize(kept);
-            (void)hipGetLastError();      // hipEventQuery reports "not ready" through the error state
-        }
     }
     return PT_OK;
 }
@@ -1929,20 +1952,25 @@ try {
     return st;
 } PT_CATCH_ALL
 
-pt_status pt_band_costs_read(pt_device *dev, uint64_t *costs, int max_bands, int *n_bands)
-try {
+// any_stream: the newest band launch of the device; otherwise the newest one enqueued on `stream`.
+static pt_status band_costs_read(pt_device *dev, bool any_stream, pt_stream stream, uint64_t *costs, int max_bands, int *n_bands)
+{
     clear_error();
     if (!dev || !costs || !n_bands || max_bands < 0) return set_error(PT_ERR_INVALID, "null argument");
     *n_bands = 0;
     PT_HIP(hipSetDevice(dev->index));
     TileSchedule *sched = nullptr;
-    int tiles_x, tiles_y, band_rows, local_rows;
-    hipStream_t hs;
+    int tiles_x = 0, tiles_y = 0, band_rows = 0, local_rows = 0;
+    hipStream_t hs = nullptr;
     {
         std::lock_guard<std::mutex> lk(dev->mu);
-        tiles_x = dev->band_tiles_x; tiles_y = dev->band_tiles_y; band_rows = dev->band_rows_last; local_rows = dev->band_local_rows;
-        hs = dev->band_stream;
-        for (TileSchedule *t : dev->schedules) if (dev->band_sched_id && t->id == dev->band_sched_id) sched = t;      // still cached? (by id: an evicted schedule's address can be reused)
+        const pt_device::BandLaunch *bl = nullptr;
+        for (const auto &e : dev->band_launches)
+            if (any_stream ? (!bl || e.stamp > bl->stamp) : e.stream == (hipStream_t)stream) bl = &e;
+        if (!bl) return PT_OK;                                 // no band launch (on that stream) yet
+        tiles_x = bl->tiles_x; tiles_y = bl->tiles_y; band_rows = bl->band_rows; local_rows = bl->local_rows;
+        hs = bl->stream;
+        for (TileSchedule *t : dev->schedules) if (bl->sched_id && t->id == bl->sched_id) sched = t;      // still cached? (by id: an evicted schedule's address can be reused)
         if (sched) sched->busy++;
     }
     if (!sched || tiles_y <= 0) return PT_OK;              // nothing recorded (tile schedule off, tiny launch, or evicted)
@@ -1974,6 +2002,16 @@ try {
     }
     *n_bands = nb;
     return PT_OK;
+}
+
+pt_status pt_band_costs_read(pt_device *dev, uint64_t *costs, int max_bands, int *n_bands)
+try {
+    return band_costs_read(dev, true, nullptr, costs, max_bands, n_bands);
+} PT_CATCH_ALL
+
+pt_status pt_band_costs_read_on(pt_device *dev, pt_stream stream, uint64_t *costs, int max_bands, int *n_bands)
+try {
+    return band_costs_read(dev, false, stream, costs, max_bands, n_bands);
 } PT_CATCH_ALL
 
 pt_status pt_stream_sync(pt_device *dev, pt_stream stream)

@@ -287,11 +287,15 @@ class DevicePathTracer:
         capi.check(capi.lib().pt_render_band_list_async(self._h, band_rows, arr, len(bands), C.byref(cam),
                                                         self.samplesPerPixel_, self.recursionDepth_, _stream_ptr(stream)))
 
-    def bandCosts(self, max_bands: int = 8192):
-        """Costs of the bands of the latest row-band launch, in launch order ([] when none were recorded)."""
+    def bandCosts(self, max_bands: int = 8192, stream=None):
+        """Costs of the bands of the latest row-band launch -- with `stream`: of the latest one enqueued on that stream
+        (frames in flight) -- in launch order ([] when none were recorded)."""
         out = (C.c_uint64 * max_bands)()
         n = C.c_int()
-        capi.check(capi.lib().pt_band_costs_read(self._h, out, max_bands, C.byref(n)))
+        if stream is None:
+            capi.check(capi.lib().pt_band_costs_read(self._h, out, max_bands, C.byref(n)))
+        else:
+            capi.check(capi.lib().pt_band_costs_read_on(self._h, _stream_ptr(stream), out, max_bands, C.byref(n)))
         return [int(out[i]) for i in range(n.value)]
 
     def waitForRenderTask(self):

@@ -303,14 +303,16 @@ class RenderManager:
     (lpt_assignment).  Images are identical under every dealer.
     """
 
-    frames_in_flight = 1          # (class defaults: one frame at a time, nothing in flight)
+    frames_in_flight = 1          # (class defaults: one frame at a time, nothing in flight, no host copies)
     frames_completed = 0
     _inflight = ()
+    host_frames = False
+    _pending_costs = None
     record_spans = False          # bench.py: a pair of timing events around every frame's launch, on the launch's stream
 
     def __init__(self, config: RendererConfig, hScene: HostScene, cameraConfig: CameraConfig,
                  device_idx: int = 0, band_rows: int = 8, streams_per_gpu: Optional[int] = None,
-                 bvh_mode: int = 0, frames_in_flight: int = 1):
+                 bvh_mode: int = 0, frames_in_flight: int = 1, host_frames: bool = False):
         import collections
         import torch
         import torch.distributed as dist
@@ -336,16 +338,30 @@ class RenderManager:
         # waves of the younger ones take the slots the oldest one's last chains leave empty.  A frame's latency grows, the
         # frame rate approaches what the work allows (an eighth of C2: 13.7 ms per frame alone, 10.3 / 8.8 ms with 2 / 3 in
         # flight; profiles/r03_frames_in_flight.json).  F + 1 framebuffers form a ring, so the last COMPLETE frame
-        # (getFramebuffer / getCurrentFrame) stays untouched until the next renderFrame().  Images are the same frames in the
-        # same order.  The cost-fed dealers (DSFL / DSDL) re-deal between consecutive frames and keep one frame in flight.
+        # (getFramebuffer / getCurrentFrame) stays untouched until the next renderFrame(); frame 0 goes into ring slot 1, so
+        # that what getFramebuffer() hands out before any frame is complete (slot 0) is never a buffer being rendered into
+        # (frameCompleted() says whether a frame is there yet; getCurrentFrame() completes one first if not).  Images are the
+        # same frames in the same order.  The cost-fed dealers (DSFL / DSDL) pipeline too: every frame in flight carries the
+        # band assignment it was launched with, the costs of a completed frame go into their all-reduce right after its
+        # exchange, and the re-deal they feed applies from the next launch on -- F - 1 frames after the frame it was
+        # measured on, on every rank alike (the wait for the all-reduce is at a fixed place in the call sequence).
         # More than three launches only overlap when each has a hardware queue of its own: the HIP runtime maps the streams
         # of a process onto 4 queues unless GPU_MAX_HW_QUEUES says otherwise BEFORE the runtime initialises (bench.py sets 8).
         self.frames_in_flight = max(1, int(frames_in_flight))
-        if self.dynamic():
-            self.frames_in_flight = 1
-        self._inflight = collections.deque()      # (framebuffer, stream) of launched, not yet completed frames, oldest first
-        self._launched = 0
-        self.frames_completed = 0                 # frames in flight: how many frames have been completed so far
+        hwq = capi.lib().pt_hw_queue_count()      # launches only overlap while each has a hardware queue of its own
+        if self.frames_in_flight > max(1, hwq):
+            self.frames_in_flight = max(1, hwq)
+        self._inflight = collections.deque()      # (framebuffer, stream, assignment, static) of launched, not yet completed frames, oldest first
+        self._launched = 1 if self.frames_in_flight > 1 else 0      # frame 0 renders into ring slot 1 (see above)
+        self.frames_completed = 0                 # how many frames have been completed so far
+        # HOST-VISIBLE FRAMES (a frame includes "gather to host-visible RGB"; the reference's host reads the managed
+        # framebuffer after renderFrame, Framebuffer.h:27-35).  With host_frames every completed frame is copied, RGB + YUV,
+        # into pinned host memory on a stream of its own, under the rendering of the next frame(s); hostFrame() waits for the
+        # latest copy.  Rank 0 only (it owns the gathered frame).
+        self.host_frames = bool(host_frames) and self.rank == 0
+        self._pins, self._delivered, self._host_latest = [], 0, -1
+        if self.host_frames:
+            self._copy_stream = torch.cuda.Stream(device=device_idx)
         if self.frames_in_flight > 1:
             self._ring = [self.framebuffer_] + [Framebuffer(config.resolution, device="cuda:%d" % device_idx)
                                                 for _ in range(self.frames_in_flight)]
@@ -399,6 +415,46 @@ class RenderManager:
     def getFramebuffer(self) -> Framebuffer:
         return self.framebuffer_
 
+    def frameCompleted(self) -> bool:
+        """Whether getFramebuffer() holds a rendered frame yet (frames in flight: the first F - 1 renderFrame() calls only
+        launch).  The C++ host's RenderManager::frameCompleted()."""
+        return self.frames_completed > 0
+
+    # -- host-visible frames
+    def _deliver(self, fb):
+        """Rank 0, host_frames: enqueue the copy of the completed frame `fb` into the next pinned pair."""
+        if not self.host_frames:
+            return
+        torch = self._torch
+        res = self.config_.resolution
+        n_rgb, n_yuv = res.width * res.height * 3, res.width * res.height * 3 // 2
+        want = max(2, self.frames_in_flight + 1)
+        if len(self._pins) != want or self._pins[0][0].numel() != n_rgb:
+            self._copy_stream.synchronize()
+            self._pins = [(torch.empty(n_rgb, dtype=torch.uint8).pin_memory(), torch.empty(n_yuv, dtype=torch.uint8).pin_memory(),
+                           torch.cuda.Event()) for _ in range(want)]
+        k = self._delivered % len(self._pins)
+        pin_rgb, pin_yuv, ev = self._pins[k]
+        cs = self._copy_stream
+        cs.wait_stream(torch.cuda.current_stream(fb.rgb.device))      # the exchange's unpacking ran on the current stream
+        with torch.cuda.stream(cs):
+            pin_rgb.copy_(fb.rgb.reshape(-1), non_blocking=True)
+            pin_yuv.copy_(fb.yuv.reshape(-1), non_blocking=True)
+            ev.record(cs)
+        fb._copy_event = ev                       # the next launch into this framebuffer waits for it
+        self._delivered += 1
+        self._host_latest = k
+
+    def hostFrame(self):
+        """(rgb, yuv) of the latest completed frame in pinned host memory, as numpy views (valid until F more frames are
+        delivered); None before the first one.  Waits for that frame's copy only."""
+        if not self.host_frames or self._host_latest < 0:
+            return None
+        pin_rgb, pin_yuv, ev = self._pins[self._host_latest]
+        ev.synchronize()
+        res = self.config_.resolution
+        return pin_rgb.numpy().reshape(res.height, res.width, 3), pin_yuv.numpy()
+
     def resetSpans(self):
         self._spans = []
 
@@ -428,6 +484,9 @@ class RenderManager:
             self._launch(stream)
 
     def _launch(self, stream):
+        ev = getattr(getattr(self.tracer, "framebuffer_", None), "_copy_event", None)      # its previous frame is still on its way to the host
+        if ev is not None and stream is not None:
+            stream.wait_event(ev)
         if self.world == 1:
             self.tracer.renderTaskAsync(self.renderTasks_[0], stream)
         elif self.static_:
@@ -439,14 +498,16 @@ class RenderManager:
         for s in self.streams:
             self.tracer.synchronizeStream(s)
 
-    def _begin_redeal(self):
+    def _begin_redeal(self, assignment=None, stream=None):
         """DSFL / DSDL in this path's form, first half (right after this rank's launch has finished): the costs of the
         bands it just rendered go into one ASYNCHRONOUS all-reduce (n_bands + 1 64-bit words) that gives every rank the
-        whole vector.  Nobody waits here -- the peers are not held up by rank 0's unpacking, and rank 0 not by them."""
+        whole vector.  Nobody waits here -- the peers are not held up by rank 0's unpacking, and rank 0 not by them.
+        Frames in flight: `assignment` / `stream` are those of the COMPLETED frame (several launches are queued; the costs
+        are read from the band launch that ran on that stream)."""
         import torch.distributed as dist
         torch = self._torch
-        mine = self.assignment_[self.rank]
-        costs = self.tracer.bandCosts()
+        mine = (assignment if assignment is not None else self.assignment_)[self.rank]
+        costs = self.tracer.bandCosts(stream=stream)
         have = torch.zeros(self.n_bands_ + 1, dtype=torch.int64)
         if len(costs) == len(mine):
             have[torch.as_tensor(mine, dtype=torch.long)] = torch.as_tensor(costs, dtype=torch.int64)
@@ -472,28 +533,39 @@ class RenderManager:
             self._refresh_tasks()
 
     def _complete_oldest(self, gather: bool):
-        """Frames in flight: wait for the oldest launched frame, run its exchange, make it the current frame."""
-        fb, stream = self._inflight.popleft()
+        """Frames in flight: wait for the oldest launched frame, run its exchange (with the band assignment IT was launched
+        with), hand its costs to the dealer, make it the current frame."""
+        fb, stream, assignment, _static = self._inflight.popleft()
         self.tracer.synchronizeStream(stream)
         if gather and self.world > 1:
             res = self.config_.resolution
-            exchange = BandGather(res.width, res.height, self.band_rows, self.assignment_, fb.rgb)
+            exchange = BandGather(res.width, res.height, self.band_rows, assignment, fb.rgb)
             # (rank 0's own bands are in place already: only the peers pack)
             packed = None if self.rank == 0 else pack_rank_bands(fb.rgb, fb.yuv, res.width, res.height, self.band_rows,
-                                                                 self.assignment_[self.rank], self._torch)
+                                                                 assignment[self.rank], self._torch)
             exchange.finish(packed, fb.rgb, fb.yuv)       # every rank: frames in launch order, one batch per frame
+            # ORDER on RCCL (see renderFrame): the frame's exchange first, its cost all-reduce after it, on every rank
+            if self.dynamic():
+                if self._pending_costs is not None:       # (flush(): several completions without a launch in between)
+                    self._finish_redeal()
+                self._begin_redeal(assignment, stream)
         self.framebuffer_ = fb
         self.frames_completed += 1
+        self._deliver(fb)
 
     def flush(self, gather: bool = True):
         """Frames in flight: complete every launched frame, oldest first (no-op otherwise).  Afterwards
         getFramebuffer() / getCurrentFrame() is the last frame launched."""
         while self._inflight:
             self._complete_oldest(gather)
+        if self.host_frames:
+            self._copy_stream.synchronize()
 
     def _render_frame_in_flight(self, gather: bool):
         torch = self._torch
         F = self.frames_in_flight
+        if self._pending_costs is not None:       # the re-deal fed by the frame completed in the previous call: from this launch on
+            self._finish_redeal()
         fb = self._ring[self._launched % (F + 1)]
         stream = self.streams[self._launched % F]
         # whatever read or unpacked this buffer last (the current stream's work) is done before the kernel writes to it
@@ -501,19 +573,17 @@ class RenderManager:
             stream.wait_stream(torch.cuda.current_stream(fb.rgb.device))
         self.tracer.setFramebuffer(fb)
         self.renderTasks(stream)
-        self._inflight.append((fb, stream))
+        self._inflight.append((fb, stream, self.assignment_, self.static_))
         self._launched += 1
         if len(self._inflight) >= F:
             self._complete_oldest(gather)
 
     def renderFrame(self, gather: bool = True):
         t0 = time.perf_counter()
-        if self.frames_in_flight > 1 and not self.dynamic():
+        if self.frames_in_flight > 1:
             self._render_frame_in_flight(gather)
             self.last_frame_ms = (time.perf_counter() - t0) * 1e3
             return
-        if self._inflight:                        # a cost-fed dealer was switched on with frames in flight: finish them, then
-            self.flush(gather)                    # one frame at a time (the last frame launched is the bound framebuffer)
         res = self.config_.resolution
         if self._pending_costs is not None:
             self._finish_redeal()                 # this frame's split, from the previous frame's costs
@@ -534,12 +604,21 @@ class RenderManager:
         # an all-reduce that waits for rank 0's, queued behind that receive.  tests/test_distributed_gloo.py pins it.
         if self.dynamic():
             self._begin_redeal()
+        self.frames_completed += 1
+        self._deliver(self.framebuffer_)
         self.last_frame_ms = (time.perf_counter() - t0) * 1e3
 
     def getCurrentFrame(self) -> np.ndarray:
+        """The last complete frame.  Frames in flight: while none is complete yet (the first F - 1 calls of renderFrame()
+        only launch) the frames launched so far are completed first -- the caller never sees a buffer that is being
+        rendered into, nor a blank one."""
+        if self.frames_completed == 0 and self._inflight:
+            self.flush()
         return self.framebuffer_.rgb_host()
 
     def getYUVFrame(self) -> np.ndarray:
+        if self.frames_completed == 0 and self._inflight:
+            self.flush()
         return self.framebuffer_.yuv_host()
 
     def reset(self):

@@ -114,12 +114,16 @@ class _FakeTracer:
     def __init__(self, pt, ref_rgb, ref_yuv, fb, W, H, band, costs):
         self.pt, self.ref_rgb, self.ref_yuv, self.fb, self.W, self.H, self.band, self.costs = pt, ref_rgb, ref_yuv, fb, W, H, band, costs
         self.last = []
+        self.launches = []               # every launch's band list, in launch order
+        self.unread = []                 # launches whose costs have not been read yet (frames complete in launch order)
 
     def _render(self, bands):
         ranges = self.pt.bands_to_ranges(self.H, self.band, bands)
         self.pt.unpack_bands(self.pt.pack_bands(self.ref_rgb, self.ref_yuv, self.W, self.H, ranges, torch),
                              self.fb.rgb, self.fb.yuv, self.W, self.H, ranges)
         self.last = list(bands)
+        self.launches.append(list(bands))
+        self.unread.append(list(bands))
 
     def renderBandsAsync(self, band_rows, world, rank, stream=None):
         self._render(list(range(rank, (self.H + band_rows - 1) // band_rows, world)))
@@ -133,8 +137,10 @@ class _FakeTracer:
     def setFramebuffer(self, fb):
         self.fb = fb
 
-    def bandCosts(self):
-        return [self.costs[b] for b in self.last]
+    def bandCosts(self, stream=None):
+        # frames in flight: the costs asked for are those of the frame being COMPLETED, the oldest launch not read yet
+        bands = self.unread.pop(0) if self.unread else self.last
+        return [self.costs[b] for b in bands]
 
     def close(self):
         pass
@@ -226,7 +232,7 @@ def _in_flight_worker(rank, world, port, W, H, band, fif, out_dir):
     mgr.config_ = pt.RendererConfig(samplesPerPixel=1, recursionDepth=1, gpuNumber=world, resolution=pt.Resolution(W, H),
                                     showTasks=False, algorithmType=pt.FSFL)
     mgr.rank, mgr.world, mgr.band_rows = rank, world, band
-    mgr.frames_in_flight, mgr.streams, mgr._inflight, mgr._launched = fif, [None] * fif, collections.deque(), 0
+    mgr.frames_in_flight, mgr.streams, mgr._inflight, mgr._launched = fif, [None] * fif, collections.deque(), 1
     mgr._ring = []
     for _ in range(fif + 1):
         fb = _FakeFb()
@@ -236,15 +242,20 @@ def _in_flight_worker(rank, world, port, W, H, band, fif, out_dir):
     mgr.tracer = _FakeTracer(pt, ref_rgb, ref_yuv, mgr._ring[0], W, H, band, _costs(n_bands, 11))
     mgr._make_tasks()
     calls, handed = [], 0
+    first_buffer = mgr.getFramebuffer()
     for frame in range(2 * fif + 3):
         log.clear()
         done = mgr.frames_completed
         mgr.renderFrame()
+        if mgr.frames_completed == 0:                      # what a caller can read before the first frame is complete
+            assert not mgr.frameCompleted() and mgr.getFramebuffer() is first_buffer
+            assert not first_buffer.rgb.any() and not first_buffer.yuv.any(), "a frame is being rendered into the buffer handed out"
         calls.append(list(log))
         assert mgr.frames_completed - done == (1 if frame >= fif - 1 else 0)
         if rank == 0 and mgr.frames_completed > done:
             cur = mgr.getFramebuffer()
-            assert cur is mgr._ring[(frame - fif + 1) % (fif + 1)]
+            assert cur is mgr._ring[(frame - fif + 2) % (fif + 1)]      # frame 0 went into ring slot 1: slot 0 (what getFramebuffer() hands
+                                                                         # out before any frame is complete) is never being rendered into
             assert torch.equal(cur.rgb, ref_rgb) and torch.equal(cur.yuv, ref_yuv), "frame %d" % frame
             cur.rgb.zero_(); cur.yuv.zero_()               # the next frame in this buffer must be rendered and exchanged afresh
             handed += 1
@@ -276,3 +287,87 @@ def test_every_rank_enqueues_the_frames_collectives_in_the_same_order(tmp_path, 
     for r in range(world):
         assert orders[r] == orders[0], (r, orders[r], orders[0])
     assert orders[0][0] == ["p2p", "all_reduce"], orders[0]      # the exchange first, the cost all-reduce after it
+
+
+def _dealer_in_flight_worker(rank, world, port, W, H, band, fif, out_dir):
+    """RenderManager under DSFL WITH frames in flight, orchestration only: every frame in flight carries the
+    band assignment it was launched with; per completed frame every rank issues its point-to-point batch and then the cost
+    all-reduce, in launch order; the re-deal fed by frame i's costs applies from frame i + F on, on every rank alike; every
+    frame rank 0 hands out is whole."""
+    import collections
+    sys.path.insert(0, ROOT)
+    pt = importlib.import_module(PKG)
+    sched = importlib.import_module(PKG + ".scheduling")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+    real_batch, real_allreduce = dist.batch_isend_irecv, dist.all_reduce
+
+    def batch(ops):
+        log.append("p2p")
+        return real_batch(ops)
+
+    def allreduce(*a, **k):
+        log.append("all_reduce")
+        return real_allreduce(*a, **k)
+
+    dist.batch_isend_irecv, dist.all_reduce = batch, allreduce
+    total = W * H
+    rng = np.random.default_rng(7)
+    ref_rgb = torch.from_numpy(rng.integers(0, 256, total * 3, dtype=np.uint8))
+    ref_yuv = torch.from_numpy(rng.integers(0, 256, total + 2 * (total // 4), dtype=np.uint8))
+    n_bands = (H + band - 1) // band
+    costs = _costs(n_bands, 11)
+    mgr = object.__new__(sched.RenderManager)
+    mgr._torch = torch
+    mgr.config_ = pt.RendererConfig(samplesPerPixel=1, recursionDepth=1, gpuNumber=world, resolution=pt.Resolution(W, H),
+                                    showTasks=False, algorithmType=pt.DSFL)
+    mgr.rank, mgr.world, mgr.band_rows = rank, world, band
+    mgr.frames_in_flight, mgr.streams, mgr._inflight, mgr._launched = fif, [None] * fif, collections.deque(), 1
+    mgr._ring = []
+    for _ in range(fif + 1):
+        fb = _FakeFb()
+        fb.rgb, fb.yuv = torch.zeros_like(ref_rgb), torch.zeros_like(ref_yuv)
+        mgr._ring.append(fb)
+    mgr.framebuffer_ = mgr._ring[0]
+    mgr.tracer = _FakeTracer(pt, ref_rgb, ref_yuv, mgr._ring[0], W, H, band, costs)
+    mgr._make_tasks()
+    n_frames = 2 * fif + 3
+    calls = []
+    for frame in range(n_frames):
+        log.clear()
+        done = mgr.frames_completed
+        mgr.renderFrame()
+        calls.append(list(log))
+        assert mgr.frames_completed - done == (1 if frame >= fif - 1 else 0)
+        if rank == 0 and mgr.frames_completed > done:
+            cur = mgr.getFramebuffer()
+            assert torch.equal(cur.rgb, ref_rgb) and torch.equal(cur.yuv, ref_yuv), "frame %d" % frame
+            cur.rgb.zero_(); cur.yuv.zero_()
+    log.clear()
+    mgr.flush()
+    calls.append(list(log))
+    if rank == 0:
+        cur = mgr.getFramebuffer()
+        assert torch.equal(cur.rgb, ref_rgb) and torch.equal(cur.yuv, ref_yuv)
+    # which assignment every frame was LAUNCHED with: the fixed split until the costs of frame 0 have gone round
+    # (completed in call F - 1, all-reduced, applied at the next launch: frame F), the dealer's from then on
+    static, dealt = pt.static_assignment(n_bands, world)[rank], pt.lpt_assignment(costs, world)[rank]
+    assert static != dealt
+    for frame, bands in enumerate(mgr.tracer.launches):
+        assert bands == (static if frame < fif else dealt), (frame, bands)
+    mgr.reset()
+    open(os.path.join(out_dir, "dealer_calls_%d.txt" % rank), "w").write(repr(calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fif", [(2, 2), (8, 3)])      # (8, 3): the shape VERDICT r3 item 5 names
+def test_cost_fed_dealer_keeps_frames_in_flight(tmp_path, world, fif):
+    mp.spawn(_dealer_in_flight_worker, args=(world, _free_port(), 64, 136, 8, fif, str(tmp_path)), nprocs=world, join=True)
+    calls = [eval((tmp_path / ("dealer_calls_%d.txt" % r)).read_text()) for r in range(world)]
+    per_frame = ["p2p", "all_reduce"]                        # the exchange first, the frame's cost all-reduce after it (RCCL: one order everywhere)
+    want = [[] if f < fif - 1 else per_frame for f in range(2 * fif + 3)] + [per_frame * (fif - 1)]
+    for r in range(world):
+        assert calls[r] == want, (r, calls[r], want)

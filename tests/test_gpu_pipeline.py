@@ -202,7 +202,7 @@ def _rank_worker(rank, world, port, W, H, spp, depth, band, out_path, algo=0, fr
     dist.destroy_process_group()
 
 
-def _rank_worker_in_flight(rank, world, port, W, H, spp, depth, band, out_path, fif):
+def _rank_worker_in_flight(rank, world, port, W, H, spp, depth, band, out_path, fif, dealer="fsfl", host_frames=False):
     import importlib
     import sys
     import torch
@@ -215,11 +215,12 @@ def _rank_worker_in_flight(rank, world, port, W, H, spp, depth, band, out_path, 
         dist.init_process_group("gloo", rank=rank, world_size=world)
     scene = pt.SceneLoader().load(os.path.join(ROOT, "models", "cornell_box.glb")).applyCornellConvention()
     cfg = pt.RendererConfig(samplesPerPixel=spp, recursionDepth=depth, gpuNumber=world,
-                            resolution=pt.Resolution(W, H), showTasks=False, algorithmType=pt.FSFL)
+                            resolution=pt.Resolution(W, H), showTasks=False, algorithmType=pt.DSFL if dealer == "dsfl" else pt.FSFL)
     mgr = pt.RenderManager(cfg, scene, pt.CameraConfig(BOX_CAMERA[0], BOX_CAMERA[1]), device_idx=0, band_rows=band,
-                           frames_in_flight=fif)
-    assert mgr.frames_in_flight == fif and len(mgr._ring) == fif + 1
-    frames, complete = 2 * fif + 3, []
+                           frames_in_flight=fif, host_frames=host_frames)
+    assert mgr.frames_in_flight == fif and len(mgr._ring) == fif + 1      # (the cost-fed dealers keep their frames in flight too)
+    frames, complete, host_ok = 2 * fif + 3, [], True
+    first_buffer = mgr.getFramebuffer()
     for i in range(frames):
         if i == fif + 2:                       # every buffer of the ring has held a frame by now: wipe them (after a flush, so
             mgr.flush()                        # that nothing in flight is touched) -- what is read from here on was rendered from here on
@@ -228,9 +229,22 @@ def _rank_worker_in_flight(rank, world, port, W, H, spp, depth, band, out_path, 
             torch.cuda.synchronize()
         done = mgr.frames_completed
         mgr.renderFrame()
+        if mgr.frames_completed == 0:
+            # nothing is complete yet -- what getFramebuffer() hands out must not be a buffer a launch is writing to
+            # (frame 0 renders into ring slot 1), and frameCompleted() says so
+            torch.cuda.synchronize()
+            assert not mgr.frameCompleted() and mgr.getFramebuffer() is first_buffer
+            assert not bool(first_buffer.rgb.any()) and not bool(first_buffer.yuv.any())
+            assert mgr.hostFrame() is None
         if rank == 0 and mgr.frames_completed > done:      # a frame was completed: it stays readable until the next renderFrame()
             complete.append(mgr.getCurrentFrame().copy())
+            if host_frames:                                # ... and its copy in pinned host memory is that frame (RGB and YUV)
+                hf = mgr.hostFrame()
+                host_ok = host_ok and hf is not None and np.array_equal(hf[0], complete[-1]) and np.array_equal(hf[1], mgr.getYUVFrame())
     mgr.flush()
+    assert host_ok, "a host-visible frame differed from the device frame"
+    if dealer == "dsfl" and world > 1:
+        assert not mgr.static_, "the dealer never took over"
     cnt = mgr.tracer.readCounters()
     tot = torch.tensor([float(cnt["segments"])], dtype=torch.float64)
     if world > 1:
@@ -246,18 +260,21 @@ def _rank_worker_in_flight(rank, world, port, W, H, spp, depth, band, out_path, 
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,fif,W,H,band", [(2, 2, 96, 64, 8), (3, 3, 64, 40, 8), (1, 2, 96, 64, 8), (4, 4, 64, 64, 8)])
-def test_frames_in_flight_render_the_same_frames(box_oracle, gpu_device, tmp_path, world, fif, W, H, band):
+@pytest.mark.parametrize("world,fif,W,H,band,dealer,host_frames", [(2, 2, 96, 64, 8, "fsfl", False), (3, 3, 64, 40, 8, "fsfl", False), (1, 2, 96, 64, 8, "fsfl", True),
+                                                                   (4, 4, 64, 64, 8, "fsfl", False), (3, 3, 64, 104, 8, "dsfl", True), (1, 3, 64, 64, 8, "fsfl", True)])
+def test_frames_in_flight_render_the_same_frames(box_oracle, gpu_device, tmp_path, world, fif, W, H, band, dealer, host_frames):
     """RenderManager(frames_in_flight = F): renderFrame() launches frame i and completes frame i - F + 1, F launches queued
     per GPU, each in its own buffer of a ring of F + 1 on its own stream, the exchange per frame in launch order.  Every
     complete frame handed out is the oracle's, every ring buffer is rendered afresh (they are wiped mid-run), the ranks'
-    segments add up to frames x the oracle's.  World 1 too: one process, no exchange."""
+    segments add up to frames x the oracle's.  World 1 too: one process, no exchange.  dealer = dsfl: the cost-fed dealer with
+    frames in flight (every frame carries the assignment it was launched with).  host_frames: every completed
+    frame is also delivered into pinned host memory (SURVEY 8d's frame) and equals the device frame."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "frame.npz")
     spp, depth = 3, 4
-    mp.spawn(_rank_worker_in_flight, args=(world, port, W, H, spp, depth, band, out, fif), nprocs=world, join=True)
+    mp.spawn(_rank_worker_in_flight, args=(world, port, W, H, spp, depth, band, out, fif, dealer, host_frames), nprocs=world, join=True)
     got = np.load(out)
     ref = box_oracle.render(BOX_CAMERA, W, H, spp, depth, threads=8)
     assert np.array_equal(got["rgb"], ref[0]) and np.array_equal(got["yuv"], ref[1])
@@ -754,3 +771,26 @@ def test_bench_line_contract(gpu_device):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["host_cpu_count"] >= c["cores"]
     assert d["value"] > 100 * c["value"] / c["cores"]                 # a GPU, not a fallback
+
+
+def test_bench_native_host_leg(gpu_device):
+    """`bench.py --host native` runs the C++ host mirror (pt_render: ONE process, a worker thread per GPU and
+    stream, pt_gather_frame) as a child and relays a line with the keys of the Python leg.  Two engines on this box's one GPU
+    (--rehearse: the gather then moves its strings with the peer-copy transport), C1's frame: the segment count is C1's exact one."""
+    import json
+    import sys
+    for extra, ranks in (([], 1), (["--gpus", "2", "--rehearse"], 2)):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--host", "native", "--config", "c1", "--steps", "3", "--warmup", "1"] + extra,
+                             capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, res.stdout[-2000:]
+        d = json.loads(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "ranks", "backend", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "frames_in_flight", "segments_per_frame", "tests_per_segment", "kernel_build_id", "host"):
+            assert k in d, k
+        assert d["metric"] == "ray-segments/s" and d["n_gpus"] == ranks and d["ranks"] == ranks and d["host"].startswith("native")
+        assert d["segments_per_frame"] == 5903674                 # C1's exact count (tests/golden/box_400x400_16spp_4b.npz)
+        assert d["value"] > 0 and d["ms_per_step"] > 0
+        if ranks == 2:
+            assert d["backend"] and not d["backend"].startswith("none"), d["backend"]      # rccl ..., or the peer-copy transport on one device
