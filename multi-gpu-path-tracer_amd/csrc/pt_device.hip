@@ -904,6 +904,12 @@ struct pt_device {
     int lean_pct = 100;           // SAH tree, cache-resident: launches of up to this % of the device's wave slots take the lean kernel (PTAMD_LEAN_PCT)
     bool deal_dense = true;       // dealt mask walk: the 8-wave build for launches of more than 2 x the device's wave slots (PTAMD_DEAL_DENSE=0: never)
     int resident_cap = 0;         // persistent kernels: at most this many workgroups per CU (PTAMD_RESIDENT; 0 = what fits)
+    // Reference trees of up to this many inner nodes take the wave-uniform stack walks (PTAMD_STACK_MAX_PAIRS).  Rounds 1-3 sent
+    // trees beyond 4 096 inner nodes to the per-lane walk ("a wave pays for the UNION of its lanes' paths"); but the reference's
+    // tree does not prune and its boxes contain the origin, so every ray visits a good part of it anyway, and the uniform walk's
+    // scalar operands beat the per-lane gather at every size measured (profiles/r04_scene_sweep.json: the terrain at 73 k ..
+    // 524 k triangles 4.4 / 10.7 / 29.1 / 58.0 s per-lane against 1.66 / 3.12 / 7.50 / 13.1 s): no limit any more.
+    int stack_max_pairs = 1 << 28;
     int sah_stack_lds = 16;       // persistent SAH kernel: stack entries per lane kept in LDS, deeper ones spill to device memory (PTAMD_SAH_STACK: 0 = all in LDS, else 11..64)
     struct Resident { const void *kern; size_t lds; int blocks; };
     std::vector<Resident> resident_blocks;      // per kernel and LDS size: workgroups one CU holds (persistent grids)
@@ -927,7 +933,7 @@ struct pt_device {
 // most of it anyway under the reference's no-pruning traversal) and ruinous for big trees.
 static int choose_walk(const pt_device *d)
 {
-    const bool mask_ok = d->n_pairs <= 64, stack_ok = d->n_pairs <= 4096;
+    const bool mask_ok = d->n_pairs <= 64, stack_ok = d->n_pairs <= (size_t)d->stack_max_pairs;
     // item = lane | slot << 6 in 16 bits; the dealt kernel always stages the shading tables in LDS (fill_params' rule)
     const bool deal_ok = mask_ok && d->n_tris <= 1024 && (d->n_tris * 48 + d->n_mats * 48 + (size_t)d->n_lights * 80) <= 16 * 1024;
     if (d->legacy_on) return d->force_walk <= 0 ? 0 : -1;      // the extension is compiled into the per-lane walk only
@@ -1025,6 +1031,7 @@ try {
     if (const char *e = getenv("PTAMD_PART_LANES")) d->part_lanes = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_SAH_SPLIT")) { const int v = atoi(e); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) d->sah_split = v; }
     if (const char *e = getenv("PTAMD_SAH_STACK")) { const int v = atoi(e); if (v == 0 || (v >= 11 && v <= 64)) { d->sah_stack_lds = v; d->sah_by_hand = true; } }
+    if (const char *e = getenv("PTAMD_STACK_MAX_PAIRS")) { const int v = atoi(e); if (v >= 64 && v <= (1 << 28)) d->stack_max_pairs = v; }
     if (const char *e = getenv("PTAMD_LEAN_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 1000) d->lean_pct = v; }
     if (const char *e = getenv("PTAMD_DEAL_DENSE")) d->deal_dense = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_RESIDENT")) { const int v = atoi(e); if (v >= 1 && v <= 16) d->resident_cap = v; }
@@ -1435,7 +1442,7 @@ try {
         int w = choose_walk(dev);
         if (w < 0) {
             dev->force_walk = saved;
-            return set_error(PT_ERR_UNSUPPORTED, "this tree is too big for the requested wave-uniform walk (mask: <= 64 inner nodes; dealt: also <= 1024 triangles; stack: <= 4096)");
+            return set_error(PT_ERR_UNSUPPORTED, "this tree is too big for the requested wave-uniform walk (mask: <= 64 inner nodes; dealt mask: also <= 1024 triangles; dealt stack: <= 65536 triangles)");
         }
         dev->walk = w;
     }

@@ -261,7 +261,8 @@ def _rank_worker_in_flight(rank, world, port, W, H, spp, depth, band, out_path, 
 
 
 @pytest.mark.parametrize("world,fif,W,H,band,dealer,host_frames", [(2, 2, 96, 64, 8, "fsfl", False), (3, 3, 64, 40, 8, "fsfl", False), (1, 2, 96, 64, 8, "fsfl", True),
-                                                                   (4, 4, 64, 64, 8, "fsfl", False), (3, 3, 64, 104, 8, "dsfl", True), (1, 3, 64, 64, 8, "fsfl", True)])
+                                                                   (4, 4, 64, 64, 8, "fsfl", False), (3, 3, 384, 168, 8, "dsfl", True),      # (336 tiles per rank: costs are recorded)
+                                                                   (1, 3, 64, 64, 8, "fsfl", True)])
 def test_frames_in_flight_render_the_same_frames(box_oracle, gpu_device, tmp_path, world, fif, W, H, band, dealer, host_frames):
     """RenderManager(frames_in_flight = F): renderFrame() launches frame i and completes frame i - F + 1, F launches queued
     per GPU, each in its own buffer of a ring of F + 1 on its own stream, the exchange per frame in launch order.  Every
