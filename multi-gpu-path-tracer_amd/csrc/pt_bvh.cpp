@@ -700,123 +700,4 @@ bool quantise_sah_quads(const std::vector<NodePair> &quads2, std::vector<QuadQ> 
     return nq * 64ull < (1ull << 32);
 }
 
-
-namespace {
-struct QuadCBuilder {
-    const std::vector<NodePair> &q;
-    std::vector<QuadC> &out;
-    std::vector<uint32_t> &slots;
-    bool ok = true;
-    QuadCBuilder(const std::vector<NodePair> &q_, std::vector<QuadC> &o, std::vector<uint32_t> &s) : q(q_), out(o), slots(s) {}
-
-    // the largest 24-bit float not above v (the record keeps the origin's upper 24 bits)
-    static bool origin_word(float v, uint32_t &word)
-    {
-        if (!std::isfinite(v)) return false;
-        union { float f; uint32_t u; } b; b.f = v;
-        if (b.u & 0x80000000u) {                              // negative: the magnitude goes UP
-            const uint32_t mag = ((b.u & 0x7FFFFFFFu) + 0xFFu) & 0xFFFFFF00u;
-            if (mag >= 0x7F800000u) return false;
-            word = mag | 0x80000000u;
-        } else {
-            word = b.u & 0xFFFFFF00u;
-        }
-        return true;
-    }
-
-    void place(uint32_t old_qi, uint32_t ni)
-    {
-        const NodePair &h0 = q[2 * (size_t)old_qi], &h1 = q[2 * (size_t)old_qi + 1];
-        const float *box[4] = {&h0.lxmin, &h0.lxmin + 6, &h1.lxmin, &h1.lxmin + 6};
-        const uint32_t link[4] = {h0.llink, h0.lcnt, h0.rlink, h0.rcnt};
-        bool present[4];
-        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int c = 0; c < 4; c++) {
-            present[c] = box[c][0] < INFINITY;
-            if (!present[c]) continue;
-            for (int a = 0; a < 3; a++) {
-                if (!std::isfinite(box[c][2 * a]) || !std::isfinite(box[c][2 * a + 1])) ok = false;
-                mn[a] = std::min(mn[a], box[c][2 * a]); mx[a] = std::max(mx[a], box[c][2 * a + 1]);
-            }
-        }
-        QuadC n{};
-        if (!ok) return;
-        uint32_t word[3];
-        for (int a = 0; a < 3; a++) {
-            if (!origin_word(mn[a] < INFINITY ? mn[a] : 0.0f, word[a])) { ok = false; return; }
-            const float org = quadc_origin(word[a]);
-            int e = 1;
-            const float ext = mx[a] > org ? mx[a] - org : 0.0f;
-            if (ext > 0.0f) {
-                int eb;
-                (void)std::frexp(ext / 255.0f, &eb);
-                e = std::min(std::max(eb + 127, 1), 254);
-            }
-            while (e < 254 && !(quadq_plane(255u, (uint32_t)e, org) >= mx[a])) e++;
-            if (mx[a] > -INFINITY && !(quadq_plane(255u, (uint32_t)e, org) >= mx[a])) { ok = false; return; }
-            word[a] |= (uint32_t)e;
-            n.org[a] = word[a];
-        }
-        // children: inner ones get consecutive records, leaves consecutive triangles
-        uint32_t n_inner = 0, n_leaf_tris = 0;
-        for (int c = 0; c < 4; c++) if (present[c]) { if (link[c] & 15u) n_leaf_tris += link[c] & 15u; else n_inner++; }
-        const uint32_t base_node = (uint32_t)out.size();
-        out.resize(out.size() + n_inner);                  // (invalidates references into `out`: n is a local copy)
-        const uint32_t base_tri = (uint32_t)slots.size();
-        if ((uint64_t)(base_node + n_inner) * sizeof(QuadC) >= (1ull << kQuadCOffsetBits) ||
-            (uint64_t)(base_tri + n_leaf_tris) * sizeof(TriC) >= (1ull << kQuadCOffsetBits)) { ok = false; return; }
-        n.base_node = base_node * (uint32_t)sizeof(QuadC);
-        n.base_tri = base_tri * (uint32_t)sizeof(TriC);
-        uint32_t inner_seen = 0, tri_seen = 0, child_old[4] = {0, 0, 0, 0}, child_new[4] = {0, 0, 0, 0};
-        for (int c = 0; c < 4; c++) {
-            if (!present[c]) continue;
-            uint32_t meta;
-            if (link[c] & 15u) {
-                const uint32_t cnt = link[c] & 15u, first = (link[c] & ~15u) / (uint32_t)sizeof(TriIsect);
-                if (cnt > 7u || tri_seen > 15u) { ok = false; return; }
-                meta = 0x80u | (cnt << 4) | tri_seen;
-                for (uint32_t k = 0; k < cnt; k++) slots.push_back(first + k);
-                tri_seen += cnt;
-            } else {
-                meta = 0x80u | inner_seen;
-                child_old[inner_seen] = link[c] / 128u; child_new[inner_seen] = base_node + inner_seen;
-                inner_seen++;
-            }
-            n.meta |= meta << (8 * c);
-            for (int a = 0; a < 3; a++) {
-                const uint32_t ex = word[a] & 0xFFu;
-                const float org = quadc_origin(word[a]);
-                union { uint32_t u; float f; } sc; sc.u = ex << 23;
-                const float lo = box[c][2 * a], hi = box[c][2 * a + 1];
-                long bl = (long)std::floor((double)(lo - org) / (double)sc.f);
-                bl = std::min(std::max(bl, 0l), 255l);
-                while (bl > 0 && !(quadq_plane((uint32_t)bl, ex, org) <= lo)) bl--;
-                while (bl < 255 && quadq_plane((uint32_t)bl + 1u, ex, org) <= lo) bl++;
-                long bh = (long)std::ceil((double)(hi - org) / (double)sc.f);
-                bh = std::min(std::max(bh, 0l), 255l);
-                while (bh < 255 && !(quadq_plane((uint32_t)bh, ex, org) >= hi)) bh++;
-                while (bh > 0 && quadq_plane((uint32_t)bh - 1u, ex, org) >= hi) bh--;
-                if (!(quadq_plane((uint32_t)bl, ex, org) <= lo) || !(quadq_plane((uint32_t)bh, ex, org) >= hi)) { ok = false; return; }
-                n.lo[a] |= (uint32_t)bl << (8 * c);
-                n.hi[a] |= (uint32_t)bh << (8 * c);
-            }
-        }
-        out[ni] = n;
-        // depth first below the run of children: a subtree's records stay together
-        for (uint32_t j = 0; j < inner_seen && ok; j++) place(child_old[j], child_new[j]);
-    }
-};
-} // namespace
-
-bool compress_sah_quads(const std::vector<NodePair> &quads2, std::vector<QuadC> &out, std::vector<uint32_t> &new_slot_to_old)
-{
-    out.clear(); new_slot_to_old.clear();
-    if (quads2.size() < 2) return false;
-    out.reserve(quads2.size() / 2);
-    out.resize(1);
-    QuadCBuilder b(quads2, out, new_slot_to_old);
-    b.place(0, 0);
-    return b.ok && out.size() == quads2.size() / 2;
-}
-
 } // namespace pt

@@ -396,8 +396,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RENDE
 __device__ unsigned long long g_occ[8];
 #endif
 
-// kForm: 0 = NodePair records, 1 = the 4-wide form (128-byte records), 2 = the 4-wide form in 64-byte records (QuadQ), 3 = in 48-byte
-// records with 36-byte triangles (QuadC / TriC).
+// kForm: 0 = NodePair records, 1 = the 4-wide form (128-byte records), 2 = the 4-wide form in 64-byte records (QuadQ).
 // kTop / kSpill (pt_walk.h): the tree's top levels in LDS and the short LDS stack with its overflow area, each compiled in
 // (1), compiled out (0) or decided per launch (2).  The kernels the library picks by itself are specialised -- a cache-resident
 // tree gets the top levels and whole stacks, a tree beyond the caches the short stack and no top levels -- because a lone
@@ -509,14 +508,12 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 #endif
                 if (want_tri >= want_node) {
                     if (sah_wants_tri(W)) {
-                        if (kForm == 3) (void)sahc_tri_step<kSpill>(P, W, L.ro, L.rd, 0.001f, stack, L.n_tri);
-                        else if (kForm != 0) (void)sahw_tri_step<kSpill>(P, W, L.ro, L.rd, 0.001f, stack, L.n_tri);
+                        if (kForm != 0) (void)sahw_tri_step<kSpill>(P, W, L.ro, L.rd, 0.001f, stack, L.n_tri);
                         else (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
                     }
                 } else {
                     if (sah_wants_node(W)) {
-                        if (kForm == 3) (void)sahc_node_step<kSpill>(P, W, L.ro, L.rd, stack, L.n_box);
-                        else if (kForm == 2) (void)sahq_node_step<kTop, kSpill>(P, W, L.ro, L.rd, stack, L.n_box);
+                        if (kForm == 2) (void)sahq_node_step<kTop, kSpill>(P, W, L.ro, L.rd, stack, L.n_box);
                         else if (kForm == 1) (void)sahw_node_step<kTop, kSpill>(P, W, L.ro, L.rd, stack, L.n_box);
                         else (void)sah_node_step(P, W, L.ro, L.rd, stack, L.n_box);
                     }
@@ -579,9 +576,6 @@ __global__ __launch_bounds__(kBlock) void render_kernel_sahw(RenderParams P) { r
 __global__ __launch_bounds__(kBlock) void render_kernel_sahw_lean(RenderParams P) { render_sah_body<1, 0, 0>(P); }
 // the 4-wide form in 64-byte records (RenderParams::sah == 3), trees beyond the caches: short LDS stack + overflow area
 __global__ __launch_bounds__(kBlock) void render_kernel_sahq(RenderParams P) { render_sah_body<2, 0, 1>(P); }
-// the 4-wide form in 48-byte records with 36-byte triangles (RenderParams::sah == 4): three requests per visit, five per pair of triangles
-__global__ __launch_bounds__(kBlock) void render_kernel_sahc(RenderParams P) { render_sah_body<3, 0, 1>(P); }
-__global__ __launch_bounds__(kBlock) void render_kernel_sahc_any(RenderParams P) { render_sah_body<3, 0, 2>(P); }
 // either form with both options decided per launch (PTAMD_SAH_TOP / PTAMD_SAH_STACK / PTAMD_SAH_QUANT set by hand, and the tests)
 __global__ __launch_bounds__(kBlock) void render_kernel_sahw_any(RenderParams P) { render_sah_body<1, 2, 2>(P); }
 __global__ __launch_bounds__(kBlock) void render_kernel_sahq_any(RenderParams P) { render_sah_body<2, 2, 2>(P); }
@@ -858,10 +852,8 @@ struct pt_device {
     int sah_top = 64;             // 4-wide forms: this many top-level records (breadth first) go first and are staged in LDS (PTAMD_SAH_TOP; 0 = none)
     uint32_t sah_top_moved = 0;   // ... how many the uploaded scene has in front
     bool sah_by_hand = false;     // PTAMD_SAH_TOP / PTAMD_SAH_STACK given: both options as asked, in the kernels that decide them per launch
-    int sah_quant = -1;           // the quantised 4-wide forms: -1 = for trees beyond 64 MB (48-byte nodes, else 64-byte), 0 = never, 1 = QuadQ always, 2 = QuadC always (PTAMD_SAH_QUANT)
+    int sah_quant = -1;           // the 4-wide form in 64-byte records (QuadQ): -1 = for trees beyond 64 MB, 0 = never, 1 = always (PTAMD_SAH_QUANT)
     bool sah_quant_on = false;    // ... and the uploaded scene has it
-    bool sah_compact_on = false;  // the uploaded scene is in the 48-byte-node form with 36-byte triangles (QuadC / TriC; sah_quant 2, or -1 beyond 64 MB)
-    uint32_t *d_ranks = nullptr;  // ... its visit ranks per slot
     bool sah_persistent = true;   // SAH walk: wave keeps stragglers' traversal state across trips
     int spec_pct = -1;            // ... and leaves the walk loop when <= this % of the walkers remain; -1 = by scene size (fill_params)
     bool deal_cap_by_hand = false; // PTAMD_DEAL_CAP given
@@ -976,7 +968,7 @@ static void free_scene(pt_device *d)
 {
     (void)hipFree(d->d_nodes); (void)hipFree(d->d_tris); (void)hipFree(d->d_shade); (void)hipFree(d->d_onb); d->d_onb = nullptr;
     (void)hipFree(d->d_lights); (void)hipFree(d->d_mats); (void)hipFree(d->d_texs);
-    (void)hipFree(d->d_texels); (void)hipFree(d->d_legacy); (void)hipFree(d->d_spheres); (void)hipFree(d->d_ranks); d->d_ranks = nullptr;
+    (void)hipFree(d->d_texels); (void)hipFree(d->d_legacy); (void)hipFree(d->d_spheres);
     d->d_legacy = nullptr; d->d_spheres = nullptr; d->n_spheres = 0; d->legacy_on = false;
     d->d_nodes = nullptr; d->d_tris = nullptr; d->d_shade = nullptr; d->d_lights = nullptr;
     d->d_mats = nullptr; d->d_texs = nullptr; d->d_texels = nullptr;
@@ -1025,7 +1017,7 @@ try {
     if (getenv("PTAMD_SAH_SIMPLE")) d->sah_persistent = false;
     if (const char *e = getenv("PTAMD_SAH_WIDE")) d->sah_wide = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_SAH_TOP")) { const int v = atoi(e); if (v >= 0 && v <= 1024) { d->sah_top = v; d->sah_by_hand = true; } }
-    if (const char *e = getenv("PTAMD_SAH_QUANT")) { const int v = atoi(e); if (v >= -1 && v <= 2) d->sah_quant = v; }
+    if (const char *e = getenv("PTAMD_SAH_QUANT")) { const int v = atoi(e); if (v >= -1 && v <= 1) d->sah_quant = v; }
     if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 99) d->spec_pct = v; }   // 100 would leave the walk loop before its first step
     if (const char *e = getenv("PTAMD_DEAL")) d->deal_auto = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_LRPT")) d->lrpt = atoi(e) != 0;
@@ -1160,10 +1152,8 @@ try {
         for (size_t i = 0; i < n; i++) bvh.indices[i] = (int)i;
     }
     SahBvh sahbvh;
-    bool sah_wide_on = false, sah_quant_on = false, sah_compact_on = false;
+    bool sah_wide_on = false, sah_quant_on = false;
     uint32_t sah_top_moved = 0;
-    std::vector<QuadC> quadc;                 // the 48-byte-node form, when it is the one uploaded
-    std::vector<int> compact_order;           // ... and its leaf order (slot -> face)
     if (sah) {
         build_sah_bvh(pos.data(), n, sahbvh);
         if (sahbvh.max_stack > 64) return set_error(PT_ERR_STACK, "SAH tree deeper than 64 levels");
@@ -1245,20 +1235,7 @@ try {
             // trees keep the 128-byte form: with their top levels in LDS (below) it is the faster one there (C3 110 ms against
             // 120 ms for the 64-byte form; the Cornell box through the SAH tree 74 against 79 ms).
             const size_t wide_bytes = pairs.size() * sizeof(NodePair) + n * sizeof(TriIsect);
-            if (dev->sah_quant == 2 || (dev->sah_quant < 0 && wide_bytes > ((size_t)64 << 20))) {
-                // 48-byte nodes + 36-byte triangles: three requests per visit and five per pair of triangles (pt_internal.h QuadC).
-                // The host reorders the node records (a node's inner children consecutive) and the triangles (a node's leaf
-                // triangles consecutive); trees it cannot express (leaves of more than 7 triangles, offsets beyond 2^29) take QuadQ.
-                std::vector<uint32_t> new_to_old;
-                if (compress_sah_quads(pairs, quadc, new_to_old) && new_to_old.size() == n) {
-                    compact_order.resize(n);
-                    for (size_t s2 = 0; s2 < n; s2++) compact_order[s2] = sahbvh.order[new_to_old[s2]];
-                    sah_compact_on = true;
-                } else {
-                    quadc.clear();
-                }
-            }
-            if (!sah_compact_on && (dev->sah_quant >= 1 || (dev->sah_quant < 0 && wide_bytes > ((size_t)64 << 20)))) {
+            if (dev->sah_quant == 1 || (dev->sah_quant < 0 && wide_bytes > ((size_t)64 << 20))) {
                 std::vector<QuadQ> qq;
                 if (quantise_sah_quads(pairs, qq)) {
                     static_assert(sizeof(QuadQ) == sizeof(NodePair), "a QuadQ record travels as one NodePair-sized record");
@@ -1275,7 +1252,7 @@ try {
             }
         }
     }
-    const std::vector<int> &slot_face = sah_compact_on ? compact_order : sah ? sahbvh.order : bvh.indices;
+    const std::vector<int> &slot_face = sah ? sahbvh.order : bvh.indices;
     std::vector<TriIsect> isect(n);
     std::vector<TriShade> shade(n);
     auto make_isect = [&](const pt_triangle &t, float *out12, float *area, float *v1v2) {
@@ -1313,24 +1290,8 @@ try {
 
     free_scene(dev);
     pt_status st;
-    if (sah_compact_on) {
-        // QuadC records and TriC records travel as raw bytes in the node / triangle buffers (+ 64 bytes behind the triangles:
-        // a lone triangle's third request reads 12 bytes past its record); the visit ranks go into their own array
-        std::vector<TriC> tc(n + 2);
-        std::vector<uint32_t> ranks(n);
-        for (size_t s2 = 0; s2 < n; s2++) {
-            memcpy(&tc[s2], &isect[s2], sizeof(TriC));          // v0, e1, e2: TriIsect's first nine floats
-            memcpy(&ranks[s2], &isect[s2].nx, 4);
-        }
-        PT_HIP(hipMalloc((void **)&dev->d_nodes, quadc.size() * sizeof(QuadC) + 64));
-        PT_HIP(hipMemcpy(dev->d_nodes, quadc.data(), quadc.size() * sizeof(QuadC), hipMemcpyHostToDevice));
-        PT_HIP(hipMalloc((void **)&dev->d_tris, tc.size() * sizeof(TriC)));
-        PT_HIP(hipMemcpy(dev->d_tris, tc.data(), tc.size() * sizeof(TriC), hipMemcpyHostToDevice));
-        if ((st = upload_vec(ranks, &dev->d_ranks)) != PT_OK) return st;
-    } else {
     if ((st = upload_vec(pairs, &dev->d_nodes)) != PT_OK) return st;
     if ((st = upload_vec(isect, &dev->d_tris)) != PT_OK) return st;
-    }
     if ((st = upload_vec(shade, &dev->d_shade)) != PT_OK) return st;
     {
         // onb::onb(normal), onb.h:8-13, per triangle: what shade() would build from the hit's normal on every scattering
@@ -1381,7 +1342,7 @@ try {
     dev->n_lights = (int)lights.size();
     dev->n_tris = n;
     dev->n_mats = m;
-    dev->n_pairs = sah_compact_on ? quadc.size() : pairs.size();
+    dev->n_pairs = pairs.size();
     // Stage the whole scene in LDS when it is small (Cornell box: 10 pairs + 36 triangles =
     // 2.4 KB); the queue holds every leaf a ray can meet when the tree is small, else 8.
     const size_t scene_bytes = pairs.size() * sizeof(NodePair) + n * sizeof(TriIsect);
@@ -1390,13 +1351,11 @@ try {
     dev->sah = sah;
     dev->sah_wide_on = sah && sah_wide_on;
     dev->sah_quant_on = sah && sah_wide_on && sah_quant_on;
-    dev->sah_compact_on = sah && sah_wide_on && sah_compact_on;
     dev->sah_top_moved = sah && sah_wide_on ? sah_top_moved : 0u;
     dev->sah_stack = sah ? sahbvh.max_stack : 0;
     if (sah && getenv("PTAMD_VERBOSE"))
         fprintf(stderr, "ptamd: SAH tree %zu pairs, %s form %zu records, walk stack %u entries\n", sahbvh.pairs.size(),
-                sah_compact_on ? "4-wide 48-byte" : sah_quant_on ? "4-wide 64-byte" : sah_wide_on ? "4-wide" : "pair",
-                sah_compact_on ? quadc.size() : sah_wide_on && !sah_quant_on ? pairs.size() / 2 : pairs.size(), sahbvh.max_stack);
+                sah_quant_on ? "4-wide 64-byte" : sah_wide_on ? "4-wide" : "pair", sah_wide_on && !sah_quant_on ? pairs.size() / 2 : pairs.size(), sahbvh.max_stack);
     dev->walk = std::max(choose_walk(dev), 0);
     dev->queue_entries = (int)std::min<uint32_t>(std::max<uint32_t>(dev->bvh.leaves + 1, 4), 12);
     dev->has_scene = true;
@@ -1529,8 +1488,7 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     P.n_pairs = (int)dev->n_pairs;
     P.n_tris = (int)dev->n_tris;
     P.queue_entries = dev->queue_entries;
-    P.sah = dev->sah ? (dev->sah_compact_on ? 4 : dev->sah_quant_on ? 3 : dev->sah_wide_on ? 2 : 1) : 0;
-    P.ranks = dev->d_ranks;
+    P.sah = dev->sah ? (dev->sah_quant_on ? 3 : dev->sah_wide_on ? 2 : 1) : 0;
     // How soon the SAH kernel's walk loop lets finished lanes shade and take their next segment.  Measured (tools/exp_pct.sh):
     // a tree that lives in the caches wants few, well-filled shading passes (C3: 40 % -> 128.8 ms; 50: 131.2, 65: 138.7);
     // a tree in HBM, whose every step waits on memory, wants its idle lanes refilled early (C4: 80 % -> 67.5 ms; 50: 72.2,
@@ -1624,7 +1582,6 @@ static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool 
         (void)scene_bytes;      // round 1 picked the 6-wave build for cache-resident scenes; after round 2's diet the natural
                                 // (5-wave, spill-free) build is as fast there (C3 132.9 vs 133.8 ms) and faster on C4
         const bool six = dev->sah_waves == 6;
-        if (dev->sah_compact_on) return dev->sah_by_hand ? PT_KERNEL(dev::render_kernel_sahc_any) : PT_KERNEL(dev::render_kernel_sahc);
         if (dev->sah_quant_on) return dev->sah_by_hand ? PT_KERNEL(dev::render_kernel_sahq_any) : PT_KERNEL(dev::render_kernel_sahq);
         if (dev->sah_wide_on) return dev->sah_by_hand ? PT_KERNEL(dev::render_kernel_sahw_any) : dense ? PT_KERNEL(dev::render_kernel_sahw6) : PT_KERNEL(dev::render_kernel_sahw);
         return six ? PT_KERNEL(dev::render_kernel_sah6) : PT_KERNEL(dev::render_kernel_sah);
@@ -1681,8 +1638,7 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     // Launches with more than twice as many tiles as the device has wave slots are bound by throughput and take the builds
     // with one more wave per SIMD (dealt mask walk: eight; dealt stack walk and the SAH kernel of cache-resident trees: six);
     // smaller ones, whose time is some wave's chain, keep the spill-free builds.
-    const bool sah_small_records = dev->sah_quant_on || dev->sah_compact_on;      // the forms of trees beyond the caches (QuadQ / QuadC)
-    const bool dense = (walk == 4 || walk == 5 || (walk == 3 && dev->sah_persistent && dev->sah_wide_on && !sah_small_records)) && dev->deal_dense &&
+    const bool dense = (walk == 4 || walk == 5 || (walk == 3 && dev->sah_persistent && dev->sah_wide_on && !dev->sah_quant_on)) && dev->deal_dense &&
                        tiles >= (walk == 4 ? 2ll * dev->max_waves : 2ll * dev->cu_count * 6 * dev::kWavesPerBlock);
     if (dense && walk == 5 && !dev->deal_cap_by_hand) P.deal_cap = 384;      // six workgroups' item lists and stacks in a CU's LDS
     // Parts of split tiles walk by lanes (part_walk_by_lanes, pt_walk.h) where the tree allows it: all 2 n_pairs hit bits in
@@ -1710,14 +1666,14 @@ static pt_status launch_render(pt_device *dev, RenderParams &P, pt_stream stream
     // 46.5 - 47.4 ms with the options in (while the whole frame takes 123 against 110 ms): such launches get the lean kernel.
     // By hand (PTAMD_SAH_TOP / _STACK): both options as asked, always.
     bool lean = false;
-    if (walk == 3 && dev->sah_persistent && dev->sah_wide_on && !sah_small_records && !dev->sah_by_hand) {
+    if (walk == 3 && dev->sah_persistent && dev->sah_wide_on && !dev->sah_quant_on && !dev->sah_by_hand) {
         const size_t lds_lean = lds_bytes(P, dev::kBlock, stage);            // P still has whole stacks and no top levels here
         const long long slots = (long long)dev->cu_count * resident_per_cu(dev, (const void *)dev::render_kernel_sahw_lean, lds_lean) * dev::kWavesPerBlock;
         lean = tiles * 100ll <= slots * (long long)dev->lean_pct;
     }
     const int stack_lds = dev->sah_stack_lds;
     const bool short_stack = !lean;
-    const bool top_levels = !lean && !dev->sah_compact_on && (dev->sah_by_hand || !dev->sah_quant_on);
+    const bool top_levels = !lean && (dev->sah_by_hand || !dev->sah_quant_on);
     if (walk == 3 && dev->sah_persistent && short_stack && stack_lds > 0 && (int)dev->sah_stack > stack_lds) {
         // The persistent SAH kernel keeps only the top of every lane's stack in LDS (SahStack, pt_walk.h): the worst-case
         // bound of a deep tree (C4: 37 entries = 38 KB per workgroup) would otherwise cap its occupancy.

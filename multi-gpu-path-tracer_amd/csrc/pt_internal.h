@@ -142,38 +142,6 @@ inline float quadq_plane(uint32_t byte, uint32_t biased_exp, float origin)
     return __builtin_fmaf((float)byte, s.f, origin);
 }
 
-// The 4-wide form in 48-byte records with 36-byte triangles (QuadC / TriC; RenderParams::sah == 4), for trees beyond the
-// caches.  What the vector-memory path charges a divergent gather is a (lane, instruction) -- a dword costs what a dwordx4
-// does (tools/ta_gather_bench.hip, profiles/r04_ta_gather.txt) -- so a visit is cheaper by every 16-byte piece it does
-// not ask for: three loads per node instead of QuadQ's four, five per pair of triangles instead of six.  To get there a
-// node stops naming its children one link each: its INNER children are consecutive records and the triangles of its LEAF
-// children are consecutive in the triangle array (the host reorders both), so one base offset each and a byte per child
-// say everything.  Child boxes: 8-bit planes as in QuadQ, against an origin kept to 24 bits (the low byte of its word holds
-// the axis' exponent); `plane = fmaf((float)byte, 2^(e - 127), origin)` and compress_sah_quads rounds every low plane down
-// and every high plane up against exactly that expression, the origin itself never above the children's minimum.
-struct QuadC {
-    uint32_t org[3];              // per axis: (bits of the origin) & 0xFFFFFF00 | biased exponent of the unit
-    uint32_t lo[3];               // per axis: the low planes of the four children, child c in byte c
-    uint32_t hi[3];               // ... the high planes
-    uint32_t meta;                // per child a byte, child c in byte c: 0 = no such child, else 0x80 | count << 4 | idx --
-                                  // count 0: inner child, record idx (0..3) of the node's run of inner children;
-                                  // count 1..7: leaf of that many triangles, starting idx (0..15) triangles into the node's run
-    uint32_t base_node;           // byte offset of the node's first inner child
-    uint32_t base_tri;            // byte offset (36-byte records) of the node's first leaf triangle
-};
-static_assert(sizeof(QuadC) == 48, "QuadC is one 48-byte record");
-struct TriC { float v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z; };      // what triangle::hit reads; the visit rank lives in a side array (needed on exact ties only)
-static_assert(sizeof(TriC) == 36, "TriC is one 36-byte record");
-// Link words of this form (the walk's stack entries): an inner child = the byte offset of its QuadC; a leaf = count << 29 |
-// the byte offset of its first TriC.  Both offsets stay below 2^29 (14.9 M triangles): compress_sah_quads returns false beyond,
-// and for leaves of more than 7 triangles or a node whose leaves hold more than 15 + 7 of them (the builder's leaves hold 4).
-constexpr uint32_t kQuadCOffsetBits = 29;
-// quads2 = collapse_sah_quads' output (before or after sah_quads_top_levels_first).  new_slot_to_old[s] = the leaf-order slot of
-// quads2's tree that ends up at slot s here.  max_stack is unchanged (same topology).
-bool compress_sah_quads(const std::vector<NodePair> &quads2, std::vector<QuadC> &out, std::vector<uint32_t> &new_slot_to_old);
-inline float quadc_origin(uint32_t word) { union { uint32_t u; float f; } s; s.u = word & 0xFFFFFF00u; return s.f; }
-inline float quadc_plane(uint32_t byte, uint32_t word) { return quadq_plane(byte, word & 0xFFu, quadc_origin(word)); }
-
 struct TexDesc { int32_t w, h; uint32_t offset /* in floats */, pad; };
 
 } // namespace pt

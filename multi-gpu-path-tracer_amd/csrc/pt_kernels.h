@@ -14,7 +14,6 @@ struct CameraBasis {          // camera.h:21-36, evaluated once per launch on th
 struct RenderParams {
     const NodePair *nodes;
     const TriIsect *tris;
-    const uint32_t *ranks;            // 48-byte-node form (sah == 4): the reference's visit rank of every leaf-order slot (read on exact ties in t only)
     const TriShade *shade;
     const float4 *onb;                // 3 x float4 per slot {a0, a1, a2, pad}: onb(normal) per triangle (dealt kernel only)
     const LightRec *lights;
@@ -55,7 +54,7 @@ struct RenderParams {
     int n_pairs, n_tris;              // array lengths (for LDS staging)
     int n_mats;                       // material records
     int spec_pct;                     // SAH kernel: leave the walk loop when <= this % of the walkers remain
-    int sah;                          // nodes/tris hold the opt-in SAH tree: 1 pair form, 2 4-wide 128-byte nodes, 3 64-byte nodes (QuadQ), 4 48-byte nodes + 36-byte triangles (QuadC / TriC)
+    int sah;                          // 1: nodes/tris hold the opt-in SAH tree (traverse_sah)
     int shade_lds;                    // 1: shade / material / light tables are staged in LDS; 2: material and light tables only
     int deal_cap;                     // dealt walk (kWalk 4): per-wave item list capacity, 0 otherwise
     int deal_min;                     // ... a leaf hit by >= this many lanes of the wave is tested in place

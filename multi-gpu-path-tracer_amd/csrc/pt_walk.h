@@ -1119,127 +1119,11 @@ __device__ __forceinline__ bool sahq_node_step(const RenderParams &P, SahWalk &W
     return sah_walking(W);
 }
 
-// ---- the 4-wide form in 48-byte records with 36-byte triangles (QuadC / TriC, pt_internal.h; RenderParams::sah == 4) --------
-// Same walk; a visit is THREE dwordx4 requests per lane, a pair of triangles five, and link words are `count << 29 | byte
-// offset` (an inner child: count 0).  The children's links are not stored: child c is record idx of the node's run of inner
-// children, or starts idx triangles into the node's run of leaf triangles (meta byte c).
-constexpr uint32_t kTriCBytes = 36, kQuadCBytes = 48, kQuadCOffsetMask = (1u << kQuadCOffsetBits) - 1u;
-// 36-byte records are only 4-byte aligned: vector loads through types that say so (global memory takes unaligned dwordx4 /
-// dwordx2 on gfx950; what the pieces cost: profiles/r04_ta_gather.txt, "x4 x4 x1 / 36 B stride")
-typedef float pt_f4u __attribute__((ext_vector_type(4), aligned(4)));
-typedef float pt_f2u __attribute__((ext_vector_type(2), aligned(4)));
-__device__ __forceinline__ void sahc_take(SahWalk &W, uint32_t x)
-{
-    if (x >> kQuadCOffsetBits) { W.k0 = x & kQuadCOffsetMask; W.n0 = x >> kQuadCOffsetBits; }
-    else W.pair = x;
-}
-template <int kSpill>
-__device__ __forceinline__ void sahc_pop(SahWalk &W, const SahStack &S)
-{
-    if (W.sp > 0 || sah_stack_refill<kSpill>(S, W)) {
-        W.sp--;
-        sahc_take(W, S.lds[W.sp * S.stride]);
-    }
-}
-__device__ __forceinline__ void sahc_child(uint32_t c8, const uint4 r0, const uint4 r1, const uint4 r2, float ox, float oy, float oz, float sx, float sy,
-                                           float sz, v3 o, v3 inv, float tbest, float &key, uint32_t &link)
-{
-    // planes: byte c of the axis' word (v_cvt_f32_ubyteN), decoded by the expression the host rounded outwards against
-    const float xmin = fmaf((float)((r0.w >> c8) & 0xffu), sx, ox), xmax = fmaf((float)((r1.z >> c8) & 0xffu), sx, ox);
-    const float ymin = fmaf((float)((r1.x >> c8) & 0xffu), sy, oy), ymax = fmaf((float)((r1.w >> c8) & 0xffu), sy, oy);
-    const float zmin = fmaf((float)((r1.y >> c8) & 0xffu), sz, oz), zmax = fmaf((float)((r2.x >> c8) & 0xffu), sz, oz);
-    float k;
-    sahw_slab(xmin, xmax, ymin, ymax, zmin, zmax, o, inv, tbest, k);
-    const uint32_t b = (r2.y >> c8) & 0xffu;
-    key = b != 0u ? k : __builtin_inff();
-    const uint32_t cnt = (b >> 4) & 7u, idx = b & 15u;
-    const bool leaf = cnt != 0u;
-    link = ((leaf ? r2.w : r2.z) + idx * (leaf ? kTriCBytes : kQuadCBytes)) | (cnt << kQuadCOffsetBits);
-}
-template <int kSpill>
-__device__ __forceinline__ bool sahc_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, const SahStack &S, uint32_t &n_box)
-{
-    uint32_t *const stack = S.lds;
-    const int stride = S.stride;
-    sah_stack_reserve<kSpill>(S, W, 3);
-    const uint4 *np = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
-    const uint4 r0 = np[0], r1 = np[1], r2 = np[2];
-    const float ox = __uint_as_float(r0.x & 0xFFFFFF00u), oy = __uint_as_float(r0.y & 0xFFFFFF00u), oz = __uint_as_float(r0.z & 0xFFFFFF00u);
-    const float sx = __uint_as_float((r0.x & 0xffu) << 23), sy = __uint_as_float((r0.y & 0xffu) << 23), sz = __uint_as_float((r0.z & 0xffu) << 23);
-    const v3 inv = W.inv;
-    float k0, k1, k2, k3;
-    uint32_t l0, l1, l2, l3;
-    sahc_child(0u, r0, r1, r2, ox, oy, oz, sx, sy, sz, o, inv, W.tbest, k0, l0);
-    sahc_child(8u, r0, r1, r2, ox, oy, oz, sx, sy, sz, o, inv, W.tbest, k1, l1);
-    sahc_child(16u, r0, r1, r2, ox, oy, oz, sx, sy, sz, o, inv, W.tbest, k2, l2);
-    sahc_child(24u, r0, r1, r2, ox, oy, oz, sx, sy, sz, o, inv, W.tbest, k3, l3);
-    n_box += 4;
-    sahw_order(k0, l0, k1, l1); sahw_order(k0, l0, k2, l2); sahw_order(k0, l0, k3, l3);
-    const float inf = __builtin_inff();
-    W.pair = kNoPair;
-    if (k3 < inf) { stack[W.sp * stride] = l3; W.sp++; }
-    if (k2 < inf) { stack[W.sp * stride] = l2; W.sp++; }
-    if (k1 < inf) { stack[W.sp * stride] = l1; W.sp++; }
-    if (k0 < inf) sahc_take(W, l0);
-    else sahc_pop<kSpill>(W, S);
-    return sah_walking(W);
-}
-// One or two pending triangles: 36 or 72 contiguous bytes, three or five requests.  An exact tie in t (a ray through a shared
-// edge) goes to the triangle the reference visits first; the visit ranks are a side array read only then.
-__device__ __forceinline__ void sahc_candidate(const RenderParams &P, SahWalk &W, bool ok, float t, float tmin, uint32_t off)
-{
-    const bool closer = ok & (t > tmin) & (t < W.tbest);
-    const bool tie = ok & (t > tmin) & (t == W.tbest) & (W.best_off != 0xFFFFFFFFu);
-    bool take = closer;
-    if (__builtin_expect(pt_any(tie), 0)) {
-        if (tie) take = P.ranks[off / kTriCBytes] < P.ranks[W.best_off / kTriCBytes];
-    }
-    if (take) { W.tbest = t; W.best_off = off; }
-}
-__device__ __forceinline__ void sahc_tri_pair(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin, uint32_t &n_tri)
-{
-    const char *tp = reinterpret_cast<const char *>(P.tris) + (size_t)W.k0;
-    const bool two = W.n0 >= 2;
-    const pt_f4u q0 = *reinterpret_cast<const pt_f4u *>(tp), q1 = *reinterpret_cast<const pt_f4u *>(tp + 16), q2 = *reinterpret_cast<const pt_f4u *>(tp + 32);
-    pt_f4u q3 = q0; pt_f2u q4 = {0.0f, 0.0f};
-    if (two) { q3 = *reinterpret_cast<const pt_f4u *>(tp + 48); q4 = *reinterpret_cast<const pt_f2u *>(tp + 64); }
-    {
-        float t, u, v;
-        const bool ok = mt_eval(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), mk3(q1.z, q1.w, q2.x), o, d, t, u, v);
-        sahc_candidate(P, W, ok, t, tmin, W.k0);
-    }
-    if (two) {
-        float t, u, v;
-        const bool ok = mt_eval(mk3(q2.y, q2.z, q2.w), mk3(q3.x, q3.y, q3.z), mk3(q3.w, q4.x, q4.y), o, d, t, u, v);
-        sahc_candidate(P, W, ok, t, tmin, W.k0 + kTriCBytes);
-    }
-    const uint32_t done = two ? 2u : 1u;
-    n_tri += done;
-    W.k0 += done * kTriCBytes; W.n0 -= done;
-}
-template <int kSpill>
-__device__ __forceinline__ bool sahc_tri_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin, const SahStack &S, uint32_t &n_tri)
-{
-    sahc_tri_pair(P, W, o, d, tmin, n_tri);
-    // a triangle trip finishes its leaf (the builder's hold up to four), as in sahw_tri_step
-    if (pt_ballot(W.n0 != 0) != 0ull) { if (W.n0 != 0) sahc_tri_pair(P, W, o, d, tmin, n_tri); }
-    if ((W.n0 == 0) & (W.pair == kNoPair)) sahc_pop<kSpill>(W, S);
-    return sah_walking(W);
-}
-
 // The finished walk's hit record.  want_uv: the scene has textures (the only reader of the barycentrics, pt_shade.h).
 __device__ __forceinline__ Hit sah_hit(const RenderParams &P, const SahWalk &W, v3 o, v3 d)
 {
     Hit h; h.t = 0.0f; h.u = 0.0f; h.v = 0.0f; h.slot = -1;
-    if (W.best_off != 0xFFFFFFFFu && P.sah == 4) {
-        h.t = W.tbest;
-        h.slot = (int)(W.best_off / kTriCBytes);
-        if (P.any_tex) {
-            const float *tp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(P.tris) + (size_t)W.best_off);
-            float t;
-            (void)mt_eval(mk3(tp[0], tp[1], tp[2]), mk3(tp[3], tp[4], tp[5]), mk3(tp[6], tp[7], tp[8]), o, d, t, h.u, h.v);
-        }
-    } else if (W.best_off != 0xFFFFFFFFu) {
+    if (W.best_off != 0xFFFFFFFFu) {
         h.t = W.tbest;
         h.slot = (int)(W.best_off / (uint32_t)sizeof(TriIsect));        // once per segment (a multiply-high by a constant)
         if (P.any_tex) {
@@ -1266,9 +1150,7 @@ __device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, f
     SahWalk W;
     sah_begin(W, d, tmax0);
     const SahStack S = {stack, stride, P.stack_cap, nullptr, nullptr, nullptr, 0u};      // the whole stack in LDS: stack_cap is out of reach
-    if (P.sah == 4) {
-        while (W.n0 != 0 ? sahc_tri_step<0>(P, W, o, d, tmin, S, n_tri) : sahc_node_step<0>(P, W, o, d, S, n_box)) {}
-    } else if (P.sah == 3) {
+    if (P.sah == 3) {
         while (W.n0 != 0 ? sahw_tri_step<0>(P, W, o, d, tmin, S, n_tri) : sahq_node_step<0, 0>(P, W, o, d, S, n_box)) {}
     } else if (P.sah == 2) {
         while (W.n0 != 0 ? sahw_tri_step<0>(P, W, o, d, tmin, S, n_tri) : sahw_node_step<0, 0>(P, W, o, d, S, n_box)) {}

@@ -211,61 +211,6 @@ int main(int argc, char **argv)
             }
         }
     }
-    // 4. the 48-byte form (compress_sah_quads): the same tree with implicit links.  Walked from the root with the device's own
-    //    link reconstruction (pt_walk.h sahc_child: child c = record idx of the node's run of inner children, or idx triangles into
-    //    its run of leaf triangles) it must reach every record once, cover every NEW slot once, name -- through new_slot_to_old --
-    //    exactly the old slots the 128-byte form's child names, in order, and every decoded box must contain its box (decoded with
-    //    the device's expression, quadc_plane) and be no looser than two units + the 24-bit origin's step.
-    std::vector<QuadC> qc;
-    std::vector<uint32_t> new_to_old;
-    if (!compress_sah_quads(q, qc, new_to_old) || qc.size() != nq || new_to_old.size() != n) { printf("compress refused the tree\n"); return 1; }
-    {
-        std::vector<int> rec_seen(nq, 0), new_seen(n, 0), old_seen(n, 0);
-        struct Pair { uint32_t old_qi, new_off; };
-        std::vector<Pair> work{{0u, 0u}};
-        double slack_c = 0.0, extent_c = 0.0;
-        while (!work.empty()) {
-            const Pair pr = work.back(); work.pop_back();
-            if (pr.new_off % sizeof(QuadC) || pr.new_off / sizeof(QuadC) >= nq) { printf("48-byte form: node offset %u is not a record\n", pr.new_off); return 1; }
-            const QuadC &z = qc[pr.new_off / sizeof(QuadC)];
-            rec_seen[pr.new_off / sizeof(QuadC)]++;
-            const Quad Q = quad_at(q, pr.old_qi);
-            for (int i = 0; i < 4; i++) {
-                const uint32_t m = (z.meta >> (8 * i)) & 0xffu;
-                if (absent(Q.box[i])) { if (m != 0) { printf("48-byte form: absent child with a meta byte\n"); return 1; } continue; }
-                if (!(m & 0x80u)) { printf("48-byte form: present child without a meta byte\n"); return 1; }
-                const uint32_t cnt = (m >> 4) & 7u, idx = m & 15u;
-                const uint32_t link = ((cnt ? z.base_tri : z.base_node) + idx * (cnt ? (uint32_t)sizeof(TriC) : (uint32_t)sizeof(QuadC))) | (cnt << kQuadCOffsetBits);
-                if (Q.link[i] & 15u) {
-                    const uint32_t old_first = (Q.link[i] & ~15u) / 48u, old_cnt = Q.link[i] & 15u;
-                    if (cnt != old_cnt) { printf("48-byte form: leaf of %u triangles, expected %u\n", cnt, old_cnt); return 1; }
-                    const uint32_t off = link & ((1u << kQuadCOffsetBits) - 1u);
-                    if (off % sizeof(TriC)) { printf("48-byte form: leaf offset %u is not a triangle record\n", off); return 1; }
-                    for (uint32_t k = 0; k < cnt; k++) {
-                        const uint32_t ns = off / (uint32_t)sizeof(TriC) + k;
-                        if (ns >= n || new_to_old[ns] != old_first + k) { printf("48-byte form: slot %u does not hold old slot %u\n", ns, old_first + k); return 1; }
-                        new_seen[ns]++; old_seen[old_first + k]++;
-                    }
-                } else {
-                    if (cnt != 0 || (link >> kQuadCOffsetBits)) { printf("48-byte form: inner child with a count\n"); return 1; }
-                    work.push_back({Q.link[i] / 128u, link});
-                }
-                const uint32_t lo_b[3] = {(z.lo[0] >> (8 * i)) & 0xffu, (z.lo[1] >> (8 * i)) & 0xffu, (z.lo[2] >> (8 * i)) & 0xffu};
-                const uint32_t hi_b[3] = {(z.hi[0] >> (8 * i)) & 0xffu, (z.hi[1] >> (8 * i)) & 0xffu, (z.hi[2] >> (8 * i)) & 0xffu};
-                for (int a = 0; a < 3; a++) {
-                    const float lo = quadc_plane(lo_b[a], z.org[a]), hi = quadc_plane(hi_b[a], z.org[a]);
-                    union { uint32_t u; float f; } unit; unit.u = (z.org[a] & 0xffu) << 23;
-                    if (!(lo <= Q.box[i][2 * a]) || !(hi >= Q.box[i][2 * a + 1])) { printf("48-byte form, quad %u child %d axis %d: decoded [%g, %g] does not contain [%g, %g]\n", pr.old_qi, i, a, lo, hi, Q.box[i][2 * a], Q.box[i][2 * a + 1]); return 1; }
-                    if (Q.box[i][2 * a] - lo > 2.0f * unit.f + 1e-6f * std::fabs(lo) || hi - Q.box[i][2 * a + 1] > 2.0f * unit.f + 1e-6f * std::fabs(hi)) { printf("48-byte form, quad %u child %d axis %d: looser than two units\n", pr.old_qi, i, a); return 1; }
-                    slack_c += (Q.box[i][2 * a] - lo) + (hi - Q.box[i][2 * a + 1]);
-                    extent_c += Q.box[i][2 * a + 1] - Q.box[i][2 * a];
-                }
-            }
-        }
-        for (size_t i = 0; i < nq; i++) if (rec_seen[i] != 1) { printf("48-byte form: record %zu reached %d times\n", i, rec_seen[i]); return 1; }
-        for (size_t i = 0; i < n; i++) if (new_seen[i] != 1 || old_seen[i] != 1) { printf("48-byte form: slot %zu covered %d / %d times\n", i, new_seen[i], old_seen[i]); return 1; }
-        printf("48-byte form ok: %zu records, adds %.2f %% to the boxes' extents\n", qc.size(), extent_c > 0 ? 100.0 * slack_c / extent_c : 0.0);
-    }
     printf("ok: %zu triangles, %zu pairs -> %zu quads, stack bound %u (pair form %u), deepest in %d rays %u, %.1f visits per ray; 64-byte form adds %.2f %% to the boxes' extents\n",
            n, b.pairs.size(), nq, bound, b.max_stack, rays, deepest, visits / rays, extent > 0 ? 100.0 * slack / extent : 0.0);
     return 0;

@@ -14,10 +14,9 @@ pytestmark = pytest.mark.gpu
 
 def _set_form(monkeypatch, wide):
     """Device form of the SAH tree: 0 = NodePair records, 1 = 4-wide nodes of 128 bytes (the default for cache-resident
-    trees), 2 = 4-wide nodes of 64 bytes with 8-bit child planes rounded outwards, 3 = 4-wide nodes of 48 bytes with implicit
-    links and 36-byte triangles (the default beyond 64 MB)."""
+    trees), 2 = 4-wide nodes of 64 bytes with 8-bit child planes rounded outwards (the default beyond 64 MB)."""
     monkeypatch.setenv("PTAMD_SAH_WIDE", "0" if wide == 0 else "1")
-    monkeypatch.setenv("PTAMD_SAH_QUANT", "2" if wide == 3 else "1" if wide == 2 else "0")
+    monkeypatch.setenv("PTAMD_SAH_QUANT", "1" if wide == 2 else "0")
 
 
 def _tracer(pt, scene, cam, W=8, H=8, spp=1, depth=1, sah=True):
@@ -29,7 +28,6 @@ def _tracer(pt, scene, cam, W=8, H=8, spp=1, depth=1, sah=True):
 
 
 @pytest.mark.parametrize("name,n,wide", [("box", 10_000_000, 1), ("duck", 10_000_000, 1), ("box", 4_000_000, 0), ("duck", 4_000_000, 0),
-                                         ("box", 10_000_000, 3), ("duck", 10_000_000, 3),
                                          ("box", 10_000_000, 2), ("duck", 10_000_000, 2)])
 def test_sah_closest_hits_equal_reference_traversal(pt, box_scene, duck_scene, gpu_device, monkeypatch, name, n, wide):
     """SURVEY 8f-1 parity gate: identical closest-hit triangle and t as the reference-topology walk on
@@ -62,7 +60,7 @@ def test_sah_closest_hits_equal_reference_traversal(pt, box_scene, duck_scene, g
     assert hits > n // 2
 
 
-@pytest.mark.parametrize("name,parts,wide", [("box", 16, 1), ("box", 64, 1), ("duck", 16, 1), ("duck", 4, 0), ("duck", 16, 2), ("duck", 16, 3), ("box", 4, 3)])
+@pytest.mark.parametrize("name,parts,wide", [("box", 16, 1), ("box", 64, 1), ("duck", 16, 1), ("duck", 4, 0), ("duck", 16, 2)])
 def test_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, duck_oracle, gpu_device, monkeypatch, name, parts, wide):
     """The SAH kernel hands its critically dear tiles to several waves (a few pixels each) from the second launch of a
     rectangle on: which wave renders a pixel must never change it.  PTAMD_SPLIT_PCT = 10 makes every launch's dearest
@@ -94,7 +92,7 @@ def test_split_tiles_never_change_a_byte(pt, box_scene, duck_scene, box_oracle, 
     tr.close()
 
 
-@pytest.mark.parametrize("wide", [1, 0, 2, 3])
+@pytest.mark.parametrize("wide", [1, 0, 2])
 @pytest.mark.parametrize("name,W,H,spp,depth", [("box", 160, 90, 8, 8), ("duck", 96, 54, 3, 8)])
 def test_sah_images_match_oracle(pt, box_scene, duck_scene, gpu_device, monkeypatch, name, W, H, spp, depth, wide):
     import os
@@ -119,7 +117,7 @@ def test_sah_images_match_oracle(pt, box_scene, duck_scene, gpu_device, monkeypa
         assert cnt["tri_tests"] * 20 < int(g["counters"][3])
 
 
-@pytest.mark.parametrize("wide", [1, 0, 2, 3])
+@pytest.mark.parametrize("wide", [1, 0, 2])
 def test_sah_stack_overflow_area_never_changes_a_byte(pt, duck_scene, gpu_device, monkeypatch, wide):
     """The persistent SAH kernel keeps the top 16 entries of every lane's stack in LDS and moves deeper ones, eight at a
     time, to device memory (SahStack).  Forced to 11 entries, rays spill all the time: frames and EVERY counter (the walk

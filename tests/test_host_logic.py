@@ -581,9 +581,7 @@ def test_sah_tree_four_wide_device_form(tmp_path):
     from the product's host sources, checked on the host -- every node reachable once, every leaf slot covered once,
     well-formed links, absent children that the slab test can never accept (an inverted box of infinities WOULD be
     accepted), the stack bound matching the worst walk order, and the walk itself (restated in the checker) finding
-    the brute-force closest hit within that bound; the 64-byte form (QuadQ) and the 48-byte form with implicit links (QuadC:
-    same topology through the device's own link reconstruction, triangles reordered node by node, decoded boxes containing
-    theirs).  The GPU suite checks the real walks bit for bit."""
+    the brute-force closest hit within that bound.  The GPU suite checks the real walk bit for bit."""
     import subprocess
     csrc = os.path.join(ROOT, "multi-gpu-path-tracer_amd", "csrc")
     exe = str(tmp_path / "quad_collapse_check")
@@ -592,11 +590,11 @@ def test_sah_tree_four_wide_device_form(tmp_path):
                     os.path.join(csrc, "pt_bvh.cpp"), os.path.join(csrc, "pt_common.cpp"), "-pthread"], check=True)
     for n, seed in ((1, 1), (2, 2), (3, 3), (4, 4), (5, 5), (9, 6), (17, 7), (37, 8), (500, 9), (3000, 10), (40000, 11)):
         r = subprocess.run([exe, str(n), str(seed)], capture_output=True, text=True)
-        assert r.returncode == 0 and "\nok:" in "\n" + r.stdout and "48-byte form ok" in r.stdout, (n, seed, r.stdout, r.stderr)
+        assert r.returncode == 0 and r.stdout.startswith("ok:"), (n, seed, r.stdout, r.stderr)
     # the same with the tree's top levels moved to the front (the layout behind PTAMD_SAH_TOP)
     for n, seed, top in ((1, 1, 8), (9, 6, 2), (500, 9, 16), (3000, 10, 64), (40000, 11, 256)):
         r = subprocess.run([exe, str(n), str(seed), str(top)], capture_output=True, text=True)
-        assert r.returncode == 0 and "\nok:" in "\n" + r.stdout, (n, seed, top, r.stdout, r.stderr)
+        assert r.returncode == 0 and r.stdout.startswith("ok:"), (n, seed, top, r.stdout, r.stderr)
 
 
 def test_missing_native_library_fails_loudly(pt, monkeypatch):
