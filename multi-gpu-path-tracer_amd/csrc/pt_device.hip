@@ -508,7 +508,8 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 #endif
                 if (want_tri >= want_node) {
                     if (sah_wants_tri(W)) {
-                        if (kForm != 0) (void)sahw_tri_step<kSpill>(P, W, L.ro, L.rd, 0.001f, stack, L.n_tri);
+                        if (kForm == 2) (void)sahw_tri_step<kSpill, true>(P, W, L.ro, L.rd, 0.001f, stack, L.n_tri);
+                        else if (kForm != 0) (void)sahw_tri_step<kSpill>(P, W, L.ro, L.rd, 0.001f, stack, L.n_tri);
                         else (void)sah_tri_step(P, W, L.ro, L.rd, 0.001f, L.n_tri);
                     }
                 } else {
@@ -575,10 +576,12 @@ __global__ __launch_bounds__(kBlock) void render_kernel_sahw(RenderParams P) { r
 // ... for launches with fewer tiles than the device has wave slots (a rank's share of a multi-GPU frame): nothing but the walk
 __global__ __launch_bounds__(kBlock) void render_kernel_sahw_lean(RenderParams P) { render_sah_body<1, 0, 0>(P); }
 // the 4-wide form in 64-byte records (RenderParams::sah == 3), trees beyond the caches: short LDS stack + overflow area
-__global__ __launch_bounds__(kBlock) void render_kernel_sahq(RenderParams P) { render_sah_body<2, 0, 1>(P); }
+// (five waves per SIMD asked for: with both records of a triangle pair in flight at once the natural allocation is 100 VGPRs,
+// one too many registers' worth for the fifth wave; held to 96 it spills one)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_kernel_sahq(RenderParams P) { render_sah_body<2, 0, 1>(P); }
 // either form with both options decided per launch (PTAMD_SAH_TOP / PTAMD_SAH_STACK / PTAMD_SAH_QUANT set by hand, and the tests)
 __global__ __launch_bounds__(kBlock) void render_kernel_sahw_any(RenderParams P) { render_sah_body<1, 2, 2>(P); }
-__global__ __launch_bounds__(kBlock) void render_kernel_sahq_any(RenderParams P) { render_sah_body<2, 2, 2>(P); }
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_kernel_sahq_any(RenderParams P) { render_sah_body<2, 2, 2>(P); }
 
 // ---- known-answer kernels (bit-exactness contract) -----------------------------------
 __global__ void kat_arith_kernel(int op, const float *a, const float *b, float *o0, float *o1, size_t n)

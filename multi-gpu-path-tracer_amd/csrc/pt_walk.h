@@ -877,8 +877,11 @@ __device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
 // the closest hit they may have produced.  Returns false when the walk is complete.
 __device__ __forceinline__ bool sah_tri_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin, uint32_t &n_tri)
 {
-    // up to TWO pending triangles per step (leaves hold up to four, stored back to back): both records are requested
-    // before either is used, so the pair costs one memory round trip and one trip of the wave's loop instead of two
+    // up to TWO pending triangles per step (leaves hold up to four, stored back to back), in one trip of the wave's loop.
+    // (The second record is loaded under `if (two)` into registers pre-set with a copy of the first: the compiler then waits
+    // for the first record before it requests the second -- two memory round trips in a row.  Trees that live in the caches
+    // keep this form: the second trip is short there and the form needs ten registers fewer, which the six-wave build of
+    // the 128-byte-node kernel has not got (16 spilled registers instead of 7 with sah_tri_step_together, C3 102.5 -> 107.8 ms).)
     const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.tris) + (size_t)W.k0);
     const bool two = W.n0 >= 2;
     const float4 ta = tp[0], tb = tp[1], tc = tp[2];
@@ -899,6 +902,43 @@ __device__ __forceinline__ bool sah_tri_step(const RenderParams &P, SahWalk &W, 
         if (ok & (t > tmin) & ((t < W.tbest) | ((t == W.tbest) & (rank < W.best_rank)))) {
             W.tbest = t; W.best_rank = rank; W.best_off = W.k0 + (uint32_t)sizeof(TriIsect);
         }
+    }
+    const uint32_t done = two ? 2u : 1u;
+    n_tri += done;
+    W.k0 += done * (uint32_t)sizeof(TriIsect); W.n0 -= done;
+    if (W.n0 == 0) { W.k0 = W.k1; W.n0 = W.n1; W.n1 = 0; }
+    return sah_walking(W);
+}
+
+// The same step with BOTH records requested before either is used: one memory round trip per pair.  For trees beyond the caches
+// (the 64-byte-node kernel), where a round trip is an HBM miss: C4 52.1 -> 47.6 ms.
+__device__ __forceinline__ bool sah_tri_step_together(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin, uint32_t &n_tri)
+{
+    // up to TWO pending triangles per step (leaves hold up to four, stored back to back): both records are requested
+    // before either is used, so the pair costs one memory round trip and one trip of the wave's loop instead of two.
+    // (Round 4 found that it did not: the second record used to be loaded under `if (two)` into registers pre-set with a
+    // copy of the first, and the copy made the compiler wait for the first record -- s_waitcnt vmcnt(0) -- BEFORE it
+    // issued the second's loads: two serial round trips per pair, four per leaf of four.  Now a lane without a second
+    // triangle simply requests its first one again (same cache line), no exec-mask region, no copies, and the updates
+    // are selects.)
+    const float4 *tp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.tris) + (size_t)W.k0);
+    const bool two = W.n0 >= 2;
+    const float4 *up = two ? tp + 3 : tp;
+    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+    const float4 ua = up[0], ub = up[1], uc = up[2];
+    {
+        float t, u, v;
+        const bool ok = mt_eval(mk3(ta.x, ta.y, ta.z), mk3(ta.w, tb.x, tb.y), mk3(tb.z, tb.w, tc.x), o, d, t, u, v);
+        const uint32_t rank = __float_as_uint(tc.y);
+        const bool take = ok & (t > tmin) & ((t < W.tbest) | ((t == W.tbest) & (rank < W.best_rank)));
+        W.tbest = take ? t : W.tbest; W.best_rank = take ? rank : W.best_rank; W.best_off = take ? W.k0 : W.best_off;
+    }
+    {
+        float t, u, v;
+        const bool ok = mt_eval(mk3(ua.x, ua.y, ua.z), mk3(ua.w, ub.x, ub.y), mk3(ub.z, ub.w, uc.x), o, d, t, u, v);
+        const uint32_t rank = __float_as_uint(uc.y);
+        const bool take = two & ok & (t > tmin) & ((t < W.tbest) | ((t == W.tbest) & (rank < W.best_rank)));
+        W.tbest = take ? t : W.tbest; W.best_rank = take ? rank : W.best_rank; W.best_off = take ? W.k0 + (uint32_t)sizeof(TriIsect) : W.best_off;
     }
     const uint32_t done = two ? 2u : 1u;
     n_tri += done;
@@ -990,15 +1030,19 @@ __device__ __forceinline__ void sahw_pop(SahWalk &W, const SahStack &S)
     }
 }
 
-template <int kSpill>
+// kTogether: both records of a pair requested before either is used (sah_tri_step_together; trees beyond the caches)
+template <int kSpill, bool kTogether = false>
 __device__ __forceinline__ bool sahw_tri_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, float tmin, const SahStack &S,
                                               uint32_t &n_tri)
 {
-    (void)sah_tri_step(P, W, o, d, tmin, n_tri);          // (k1 / n1 are never set in this form: the range just ends)
+    if (kTogether) (void)sah_tri_step_together(P, W, o, d, tmin, n_tri);
+    else (void)sah_tri_step(P, W, o, d, tmin, n_tri);      // (k1 / n1 are never set in this form: the range just ends)
     // A triangle trip finishes its leaf (<= 4 triangles) instead of leaving the second pair to another vote: the same tests
     // in the same order for the lane, one trip of the wave less (C3 110.3 -> 106.9 ms, C4 52.8 -> 51.5 ms).  Going on with a
     // leaf that comes off the stack right after it loses: C3 129 ms, C4 60 ms.
-    if (pt_ballot(W.n0 != 0) != 0ull) { if (W.n0 != 0) (void)sah_tri_step(P, W, o, d, tmin, n_tri); }
+    if (pt_ballot(W.n0 != 0) != 0ull) {
+        if (W.n0 != 0) { if (kTogether) (void)sah_tri_step_together(P, W, o, d, tmin, n_tri); else (void)sah_tri_step(P, W, o, d, tmin, n_tri); }
+    }
     if ((W.n0 == 0) & (W.pair == kNoPair)) sahw_pop<kSpill>(W, S);
     return sah_walking(W);
 }
@@ -1036,9 +1080,25 @@ __device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W
         const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
         q0 = np[0]; q1 = np[1]; q2 = np[2]; lk = np[3]; q4 = np[4]; q5 = np[5]; q6 = np[6];
     } else {
+        // A lane's record comes from the workgroup's LDS copy of the top levels or from memory.  Written as a select per float4
+        // (`in_top ? lds[k] : global[k]`) the compiler selects the POINTER and fetches through seven flat_load_dwordx4 -- every
+        // request then goes down both the LDS and the vector-memory path and is waited for on both counters (and the first two
+        // were waited for before the other five were issued).  Two address spaces, two exec-masked groups of loads, one wait:
+        typedef const __attribute__((address_space(3))) pt_f4 *LdsF4Ptr;
+        typedef const __attribute__((address_space(1))) pt_f4 *GlobalF4Ptr;
         const uint32_t off = W.pair;
-        q0 = PT_NODE_F4(S, P, off, 0); q1 = PT_NODE_F4(S, P, off, 1); q2 = PT_NODE_F4(S, P, off, 2); lk = PT_NODE_F4(S, P, off, 3);
-        q4 = PT_NODE_F4(S, P, off, 4); q5 = PT_NODE_F4(S, P, off, 5); q6 = PT_NODE_F4(S, P, off, 6);
+        const bool in_top = off < S.top_bytes;
+        pt_f4 r0, r1, r2, r3, r4, r5, r6;
+        if (!in_top) {
+            GlobalF4Ptr g = (GlobalF4Ptr)(reinterpret_cast<const char *>(P.nodes) + (size_t)off);
+            r0 = g[0]; r1 = g[1]; r2 = g[2]; r3 = g[3]; r4 = g[4]; r5 = g[5]; r6 = g[6];
+        } else {
+            LdsF4Ptr t = (LdsF4Ptr)(S.top) + off / 16u;
+            r0 = t[0]; r1 = t[1]; r2 = t[2]; r3 = t[3]; r4 = t[4]; r5 = t[5]; r6 = t[6];
+        }
+        q0 = make_float4(r0.x, r0.y, r0.z, r0.w); q1 = make_float4(r1.x, r1.y, r1.z, r1.w); q2 = make_float4(r2.x, r2.y, r2.z, r2.w);
+        lk = make_float4(r3.x, r3.y, r3.z, r3.w); q4 = make_float4(r4.x, r4.y, r4.z, r4.w); q5 = make_float4(r5.x, r5.y, r5.z, r5.w);
+        q6 = make_float4(r6.x, r6.y, r6.z, r6.w);
     }
     const v3 inv = W.inv;
     float k0, k1, k2, k3;
@@ -1151,7 +1211,7 @@ __device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, f
     sah_begin(W, d, tmax0);
     const SahStack S = {stack, stride, P.stack_cap, nullptr, nullptr, nullptr, 0u};      // the whole stack in LDS: stack_cap is out of reach
     if (P.sah == 3) {
-        while (W.n0 != 0 ? sahw_tri_step<0>(P, W, o, d, tmin, S, n_tri) : sahq_node_step<0, 0>(P, W, o, d, S, n_box)) {}
+        while (W.n0 != 0 ? sahw_tri_step<0, true>(P, W, o, d, tmin, S, n_tri) : sahq_node_step<0, 0>(P, W, o, d, S, n_box)) {}
     } else if (P.sah == 2) {
         while (W.n0 != 0 ? sahw_tri_step<0>(P, W, o, d, tmin, S, n_tri) : sahw_node_step<0, 0>(P, W, o, d, S, n_box)) {}
     } else {

@@ -140,6 +140,9 @@ def test_c4_scale_closest_hit_gate(pt, ob, terrain, gpu_device):
     t0 = time.perf_counter()
     t_sah, f_sah = sah_tr.katClosestHit(org, dirs)
     t_sah_s = time.perf_counter() - t0
+    nb, nt = sah_tr.katWalkCost(org[:200_000], dirs[:200_000])          # (diagnostic entry point: tests per ray of the same walk)
+    print("SAH walk: %.1f box and %.1f triangle tests per ray (max %d / %d)" % (nb.mean(), nt.mean(), nb.max(), nt.max()))
+    assert 8 < nb.mean() < 400 and nt.mean() < 100 and nb.max() < 20000
     sah_tr.close()
     ref_tr = pt.DevicePathTracer(0, 1, 1, (8, 8), terrain, fb, pt.CameraConfig(*TERRAIN_CAMERA), bvhMode=0)
     t_ref, f_ref = np.empty_like(t_sah), np.empty_like(f_sah)
