@@ -578,7 +578,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel_sahw_lean(RenderParams P
 // the 4-wide form in 64-byte records (RenderParams::sah == 3), trees beyond the caches: short LDS stack + overflow area
 // (five waves per SIMD asked for: with both records of a triangle pair in flight at once the natural allocation is 100 VGPRs,
 // one too many registers' worth for the fifth wave; held to 96 it spills one)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_kernel_sahq(RenderParams P) { render_sah_body<2, 0, 1>(P); }
+#ifndef PT_SAHQ_WAVES
+#define PT_SAHQ_WAVES 5
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SAHQ_WAVES, PT_SAHQ_WAVES))) void render_kernel_sahq(RenderParams P) { render_sah_body<2, 0, 1>(P); }
 // either form with both options decided per launch (PTAMD_SAH_TOP / PTAMD_SAH_STACK / PTAMD_SAH_QUANT set by hand, and the tests)
 __global__ __launch_bounds__(kBlock) void render_kernel_sahw_any(RenderParams P) { render_sah_body<1, 2, 2>(P); }
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_kernel_sahq_any(RenderParams P) { render_sah_body<2, 2, 2>(P); }
