@@ -564,7 +564,6 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
 // spills (C3 143 -> 136 ms); the 1 GB terrain is bound by memory latency per dependent step and loses
 // to the spills (C4 84 -> 88 ms), so it keeps the natural allocation.
 __global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P) { render_sah_body<0>(P); }
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_sah6(RenderParams P) { render_sah_body<0>(P); }
 // the 4-wide form of the tree (RenderParams::sah == 2), cache-resident trees: top levels in LDS, short stack (24 KB per
 // workgroup on the duck; whole stacks + the top levels would be 35 KB, four workgroups per CU), built for SIX waves per SIMD
 // (80 VGPRs, 28 B of scratch per lane): such trees are bound by instruction issue, and with the LDS out of the way the sixth
@@ -864,7 +863,6 @@ struct pt_device {
     int spec_pct = -1;            // ... and leaves the walk loop when <= this % of the walkers remain; -1 = by scene size (fill_params)
     bool deal_cap_by_hand = false; // PTAMD_DEAL_CAP given
     int deal_cap = 768, deal_min = 48;   // dealt walk (kWalk 4): item list capacity per wave; in-place threshold (lanes)
-    int sah_waves = 0;            // SAH kernel build: 0 = by scene size, 5 / 6 = force (PTAMD_SAH_WAVES, A/B runs)
     int lrpt = 1;                 // dealt kernel: issue priority by remaining samples (PTAMD_LRPT=0: off)
     bool deal_auto = true;        // automatic choice prefers the dealt walk over the plain mask walk (PTAMD_DEAL=0: off)
     bool any_tex = false;
@@ -1027,7 +1025,6 @@ try {
     if (const char *e = getenv("PTAMD_SPEC_PCT")) { const int v = atoi(e); if (v >= 0 && v <= 99) d->spec_pct = v; }   // 100 would leave the walk loop before its first step
     if (const char *e = getenv("PTAMD_DEAL")) d->deal_auto = atoi(e) != 0;
     if (const char *e = getenv("PTAMD_LRPT")) d->lrpt = atoi(e) != 0;
-    if (const char *e = getenv("PTAMD_SAH_WAVES")) { const int v = atoi(e); if (v == 5 || v == 6) d->sah_waves = v; }
     if (const char *e = getenv("PTAMD_DEAL_MIN")) { const int v = atoi(e); if (v >= 0 && v <= 65) d->deal_min = v; }
     if (const char *e = getenv("PTAMD_DEAL_CAP")) { const int v = atoi(e); if (v >= 64 && v <= 8192) { d->deal_cap = v & ~7; d->deal_cap_by_hand = true; } }
     if (const char *e = getenv("PTAMD_SCHED_MIN_BLOCKS")) { const int v = atoi(e); if (v >= 1 && v <= 1 << 20) d->sched_min_blocks = v; }
@@ -1584,13 +1581,9 @@ static KernelChoice pick_kernel(const pt_device *dev, int walk, bool coop, bool 
     if (dense && walk == 4 && dev->deal_min <= 64) return PT_KERNEL(dev::render_kernel_dealt8);
     if (dense && walk == 5 && !coop) return PT_KERNEL(dev::render_kernel_dealt_stack6);
     if (walk == 3 && dev->sah_persistent) {
-        const size_t scene_bytes = dev->n_pairs * sizeof(NodePair) + dev->n_tris * sizeof(TriIsect);
-        (void)scene_bytes;      // round 1 picked the 6-wave build for cache-resident scenes; after round 2's diet the natural
-                                // (5-wave, spill-free) build is as fast there (C3 132.9 vs 133.8 ms) and faster on C4
-        const bool six = dev->sah_waves == 6;
         if (dev->sah_quant_on) return dev->sah_by_hand ? PT_KERNEL(dev::render_kernel_sahq_any) : PT_KERNEL(dev::render_kernel_sahq);
         if (dev->sah_wide_on) return dev->sah_by_hand ? PT_KERNEL(dev::render_kernel_sahw_any) : dense ? PT_KERNEL(dev::render_kernel_sahw6) : PT_KERNEL(dev::render_kernel_sahw);
-        return six ? PT_KERNEL(dev::render_kernel_sah6) : PT_KERNEL(dev::render_kernel_sah);
+        return PT_KERNEL(dev::render_kernel_sah);
     }
     if (walk == 3) return PT_KERNEL(dev::render_kernel<false, true, 3>);
     if (walk == 1) return PT_KERNEL(dev::render_kernel<false, true, 1>);
