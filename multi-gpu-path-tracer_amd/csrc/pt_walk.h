@@ -1153,6 +1153,16 @@ __device__ __forceinline__ void sahq_node_eval(SahWalk &W, v3 o, const SahStack 
     sahq_slab(__float_as_uint(q1.z), __float_as_uint(q2.z), q0.x, q0.y, q0.z, sx, sy, sz, o, inv, W.tbest, l2 != 0xFFFFFFFFu, k2);
     sahq_slab(__float_as_uint(q1.w), __float_as_uint(q2.w), q0.x, q0.y, q0.z, sx, sy, sz, o, inv, W.tbest, l3 != 0xFFFFFFFFu, k3);
     n_box += 4;
+#ifdef PT_PAD_NODE
+    // diagnostic build only (EXPERIMENTS.md, round 4 "what bounds a trip"): PT_PAD_NODE extra independent multiplies per
+    // visit, to read the slope of frame time against VALU instructions; never compiled into the shipped library
+    {
+        float pad = k0;
+#pragma unroll
+        for (int i = 0; i < PT_PAD_NODE; i++) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(pad));
+        if (pad == 1.2345e-30f) k0 = pad;          // (never true for a slab key; keeps the chain alive)
+    }
+#endif
     sahw_order(k0, l0, k1, l1); sahw_order(k0, l0, k2, l2); sahw_order(k0, l0, k3, l3);
     const float inf = __builtin_inff();
     W.pair = kNoPair;
@@ -1175,6 +1185,17 @@ __device__ __forceinline__ bool sahq_node_step(const RenderParams &P, SahWalk &W
         const uint32_t off = W.pair;
         q0 = PT_NODE_F4(S, P, off, 0); q1 = PT_NODE_F4(S, P, off, 1); q2 = PT_NODE_F4(S, P, off, 2); lk = PT_NODE_F4(S, P, off, 3);
     }
+#ifdef PT_PAD_LOAD
+    // diagnostic build only: PT_PAD_LOAD extra requests per visit for pieces of the same record through an address the
+    // compiler cannot see through (no common-subexpression), to read the slope of frame time against vector-memory requests
+    {
+        uint32_t off2 = W.pair;
+        asm volatile("" : "+v"(off2));
+        const float4 *np2 = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)off2);
+#pragma unroll
+        for (int i = 0; i < PT_PAD_LOAD; i++) { const float4 e = np2[i & 3]; if (e.x == 1.2345e-30f) q0.x = e.y; }
+    }
+#endif
     sahq_node_eval<kSpill>(W, o, S, q0, q1, q2, lk, n_box);
     return sah_walking(W);
 }
