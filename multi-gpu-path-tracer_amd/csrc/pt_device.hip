@@ -485,6 +485,7 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
                 } else {
                     begins = true;
                     sah_begin(W, L.rd, 3.402823466e+38f);
+                    if (kForm == 2) sahq_begin(W);
                 }
             }
             wave_seg += (uint32_t)__builtin_popcountll(pt_ballot(begins));

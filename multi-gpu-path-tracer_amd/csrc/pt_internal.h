@@ -1,6 +1,7 @@
 // pt_internal.h -- host-side internals shared by the C-ABI translation units.
 #pragma once
 
+#include <cmath>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -135,11 +136,46 @@ struct QuadQ {
 static_assert(sizeof(QuadQ) == 64, "QuadQ is one 64-byte record");
 // quads2 = collapse_sah_quads' output.  Returns false if some box cannot be represented (non-finite bounds).
 bool quantise_sah_quads(const std::vector<NodePair> &quads2, std::vector<QuadQ> &out);
-// The decode the device uses (pt_walk.h sahq_node_step), for the builder's outward rounding and the CPU checks.
+// The plane a byte stands for, one rounding away from origin + byte * unit: what the builder rounds outwards against and
+// the CPU checks decode with.  (The device never forms it: quadq_ray below.)
 inline float quadq_plane(uint32_t byte, uint32_t biased_exp, float origin)
 {
     union { uint32_t u; float f; } s; s.u = biased_exp << 23;
     return __builtin_fmaf((float)byte, s.f, origin);
+}
+
+// The ray parameters the device computes for a QuadQ child (pt_walk.h sahq_node_eval / sahq_slab), restated for the CPU
+// checks (tests/native/quad_collapse_check.cpp): per visit a slope a = unit * inv and an offset c = (origin - o) * inv per axis,
+// the offset lowered for near planes and raised for far planes by 2^-22 of its magnitude (that bounds the two roundings of c);
+// per plane t = fma(byte, a, offset).  inv must be clamped to +-2^100 (sahq_begin).
+struct QuadqRay { float a[3], near_off[3], far_off[3]; bool neg[3]; };
+inline float quadq_clamp_inv(float inv) { const float big = 1.2676506002282294e30f; return std::fmin(std::fmax(inv, -big), big); }
+inline QuadqRay quadq_ray(const QuadQ &q, const float o[3], const float inv[3])
+{
+    QuadqRay r;
+    const float org[3] = {q.ox, q.oy, q.oz};
+    for (int k = 0; k < 3; k++) {
+        union { uint32_t u; float f; } unit; unit.u = ((q.exps >> (8 * k)) & 0xffu) << 23;
+        r.a[k] = unit.f * inv[k];
+        const float c = (org[k] - o[k]) * inv[k];
+        r.near_off[k] = __builtin_fmaf(-std::fabs(c), 2.384185791015625e-07f, c);
+        r.far_off[k] = __builtin_fmaf(std::fabs(c), 2.384185791015625e-07f, c);
+        r.neg[k] = std::signbit(inv[k]);
+    }
+    return r;
+}
+// entry / exit parameters of child `c` (the key of the visit is tn if tf >= max(tn, 0) and tn <= the closest hit so far)
+inline void quadq_child_span(const QuadQ &q, int c, const QuadqRay &r, float &tn, float &tf)
+{
+    const uint32_t lo[3] = {q.lo[c] & 0xffu, (q.lo[c] >> 8) & 0xffu, (q.lo[c] >> 16) & 0xffu};
+    const uint32_t hi[3] = {q.lo[c] >> 24, q.hi[c] & 0xffu, (q.hi[c] >> 8) & 0xffu};
+    float t_near[3], t_far[3];
+    for (int k = 0; k < 3; k++) {
+        t_near[k] = __builtin_fmaf((float)(r.neg[k] ? hi[k] : lo[k]), r.a[k], r.near_off[k]);
+        t_far[k] = __builtin_fmaf((float)(r.neg[k] ? lo[k] : hi[k]), r.a[k], r.far_off[k]);
+    }
+    tn = std::fmax(std::fmax(t_near[0], t_near[1]), t_near[2]);
+    tf = std::fmin(std::fmin(t_far[0], t_far[1]), t_far[2]);
 }
 
 struct TexDesc { int32_t w, h; uint32_t offset /* in floats */, pad; };

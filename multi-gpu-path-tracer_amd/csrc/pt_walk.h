@@ -788,6 +788,7 @@ struct SahWalk {
     v3 inv;
     uint32_t k0, n0, k1, n1;      // pending leaf triangles (byte offset, count): range 0 first, then range 1
     uint32_t spill;               // blocks of 8 entries this lane's stack has moved out of LDS (SahStack; almost always 0)
+    uint32_t sel;                 // 64-byte form only (sahq_begin): v_perm selector of a child's three NEAR plane bytes
 #ifdef PT_STALE
     uint32_t stale, visits;       // diagnostic build: node visits that found both children beyond the closest hit / all visits
 #endif
@@ -866,6 +867,19 @@ __device__ __forceinline__ void sah_begin(SahWalk &W, v3 d, float tmax0)
     W.best_off = 0xFFFFFFFFu;
     W.k0 = W.n0 = W.k1 = W.n1 = 0;
     W.spill = 0;
+    W.sel = 0;
+}
+
+// The 64-byte form's additions to sah_begin (sahq_node_eval): reciprocals clamped to +-2^100 -- an exactly axis-parallel ray
+// (get_ray's cancellation produces ~2 400 of them per C4 frame) then has a finite slope and byte * (unit * inv) can never be
+// 0 * inf -- and the byte selector that picks, per axis, the plane the ray meets first.
+constexpr uint32_t kSahqFarXor = 0x00070503u;       // near selector ^ this = far selector (x: 0 <-> 3, y: 1 <-> 4, z: 2 <-> 5)
+__device__ __forceinline__ void sahq_begin(SahWalk &W)
+{
+    const float big = 1.2676506002282294e30f;        // 2^100
+    W.inv = mk3(fminf(fmaxf(W.inv.x, -big), big), fminf(fmaxf(W.inv.y, -big), big), fminf(fmaxf(W.inv.z, -big), big));
+    // bytes of {hi, lo}: 0 xlo, 1 ylo, 2 zlo, 3 xhi, 4 yhi, 5 zhi; 0x0c = constant zero
+    W.sel = 0x0c020100u ^ ((__float_as_uint(W.inv.x) >> 31) * 0x03u) ^ ((__float_as_uint(W.inv.y) >> 31) * 0x0500u) ^ ((__float_as_uint(W.inv.z) >> 31) * 0x070000u);
 }
 
 // One MICRO-step of the SAH walk: either one Moller-Trumbore test (if this lane has leaf triangles
@@ -1123,19 +1137,27 @@ __device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W
 }
 
 // ---- the 4-wide form in 64-byte records (QuadQ, pt_internal.h; RenderParams::sah == 3) ------------------------------------
-// Same walk, same stack entries; a visit costs four dwordx4 requests per lane instead of seven, plus the decode: the planes
-// are fmaf(byte, unit, origin), exactly the expression the host rounded outwards against, then the slab arithmetic of
-// sahw_slab.  (Folding the decode into the slab -- byte * (unit * inv) + (origin - o) * inv -- would save a third of the
-// arithmetic and lose the cancellation-free subtraction plane - o: for rays nearly parallel to an axis the two products
-// are huge and their sum is noise.)
-__device__ __forceinline__ void sahq_slab(uint32_t lo, uint32_t hi, float ox, float oy, float oz, float sx, float sy, float sz, v3 o, v3 inv,
-                                          float tbest, bool present, float &key)
+// Same walk, same stack entries; a visit costs four dwordx4 requests per lane instead of seven.  A plane is
+// origin + byte * unit (unit a power of two), so its ray parameter is byte * (unit * inv) + (origin - o) * inv: per visit
+// three slopes and three offsets, per plane one conversion and one fma.  Which of a child's two planes per axis the ray meets
+// first is the sign of inv, the same for every node: v_perm_b32 gathers the three near bytes and the three far bytes (W.sel),
+// which replaces the six min / max of the symmetric slab test.  Round 4 measured the slope: 0.09 ms of a C4 frame per VALU
+// instruction of a visit (profiles/r04_c4_visit_slope.json); this form has 140 where the decode-then-slab form had 193.
+// Rounding.  Against the exact parameter of the decoded plane the offset carries two roundings relative to |origin - o|
+// (the subtraction, the product), which the unfolded form did not have: the near offsets are lowered and the far offsets
+// raised by 2^-22 of their magnitude, which bounds both; the last rounding (the fma's, relative to t itself) is of the
+// kind every form has and is covered, like the difference between slab and Moller-Trumbore arithmetic, by the builder's
+// inflation of every box (pt_bvh.cpp: 1e-4 of the scene's extent + 1e-5 of its coordinates' magnitude).
+__device__ __forceinline__ void sahq_slab(uint32_t lo, uint32_t hi, uint32_t sel_n, uint32_t sel_f, float ax, float ay, float az,
+                                          float nx, float ny, float nz, float fx, float fy, float fz, float tbest, bool present, float &key)
 {
-    const float xmin = fmaf((float)(lo & 0xffu), sx, ox), ymin = fmaf((float)((lo >> 8) & 0xffu), sy, oy), zmin = fmaf((float)((lo >> 16) & 0xffu), sz, oz);
-    const float xmax = fmaf((float)(lo >> 24), sx, ox), ymax = fmaf((float)(hi & 0xffu), sy, oy), zmax = fmaf((float)((hi >> 8) & 0xffu), sz, oz);
-    float k;
-    sahw_slab(xmin, xmax, ymin, ymax, zmin, zmax, o, inv, tbest, k);
-    key = present ? k : __builtin_inff();
+    const uint32_t bn = __builtin_amdgcn_perm(hi, lo, sel_n), bf = __builtin_amdgcn_perm(hi, lo, sel_f);
+    const float t1 = fmaf((float)(bn & 0xffu), ax, nx), t3 = fmaf((float)((bn >> 8) & 0xffu), ay, ny), t5 = fmaf((float)((bn >> 16) & 0xffu), az, nz);
+    const float t2 = fmaf((float)(bf & 0xffu), ax, fx), t4 = fmaf((float)((bf >> 8) & 0xffu), ay, fy), t6 = fmaf((float)((bf >> 16) & 0xffu), az, fz);
+    const float tn = fmaxf(fmaxf(t1, t3), t5);
+    const float tf = fminf(fminf(t2, t4), t6);
+    const bool hit = (tf >= fmaxf(tn, 0.0f)) & (tn <= tbest);
+    key = (present & hit) ? tn : __builtin_inff();
 }
 
 template <int kSpill>
@@ -1147,15 +1169,21 @@ __device__ __forceinline__ void sahq_node_eval(SahWalk &W, v3 o, const SahStack 
     const float sx = __uint_as_float((exps & 0xffu) << 23), sy = __uint_as_float(((exps >> 8) & 0xffu) << 23), sz = __uint_as_float(((exps >> 16) & 0xffu) << 23);
     uint32_t l0 = __float_as_uint(lk.x), l1 = __float_as_uint(lk.y), l2 = __float_as_uint(lk.z), l3 = __float_as_uint(lk.w);
     const v3 inv = W.inv;
+    const float ax = sx * inv.x, ay = sy * inv.y, az = sz * inv.z;
+    const float cx = (q0.x - o.x) * inv.x, cy = (q0.y - o.y) * inv.y, cz = (q0.z - o.z) * inv.z;
+    const float m = 2.384185791015625e-07f;          // 2^-22
+    const float nx = fmaf(-fabsf(cx), m, cx), ny = fmaf(-fabsf(cy), m, cy), nz = fmaf(-fabsf(cz), m, cz);
+    const float fx = fmaf(fabsf(cx), m, cx), fy = fmaf(fabsf(cy), m, cy), fz = fmaf(fabsf(cz), m, cz);
+    const uint32_t sel_n = W.sel, sel_f = W.sel ^ kSahqFarXor;
     float k0, k1, k2, k3;
-    sahq_slab(__float_as_uint(q1.x), __float_as_uint(q2.x), q0.x, q0.y, q0.z, sx, sy, sz, o, inv, W.tbest, l0 != 0xFFFFFFFFu, k0);
-    sahq_slab(__float_as_uint(q1.y), __float_as_uint(q2.y), q0.x, q0.y, q0.z, sx, sy, sz, o, inv, W.tbest, l1 != 0xFFFFFFFFu, k1);
-    sahq_slab(__float_as_uint(q1.z), __float_as_uint(q2.z), q0.x, q0.y, q0.z, sx, sy, sz, o, inv, W.tbest, l2 != 0xFFFFFFFFu, k2);
-    sahq_slab(__float_as_uint(q1.w), __float_as_uint(q2.w), q0.x, q0.y, q0.z, sx, sy, sz, o, inv, W.tbest, l3 != 0xFFFFFFFFu, k3);
+    sahq_slab(__float_as_uint(q1.x), __float_as_uint(q2.x), sel_n, sel_f, ax, ay, az, nx, ny, nz, fx, fy, fz, W.tbest, l0 != 0xFFFFFFFFu, k0);
+    sahq_slab(__float_as_uint(q1.y), __float_as_uint(q2.y), sel_n, sel_f, ax, ay, az, nx, ny, nz, fx, fy, fz, W.tbest, l1 != 0xFFFFFFFFu, k1);
+    sahq_slab(__float_as_uint(q1.z), __float_as_uint(q2.z), sel_n, sel_f, ax, ay, az, nx, ny, nz, fx, fy, fz, W.tbest, l2 != 0xFFFFFFFFu, k2);
+    sahq_slab(__float_as_uint(q1.w), __float_as_uint(q2.w), sel_n, sel_f, ax, ay, az, nx, ny, nz, fx, fy, fz, W.tbest, l3 != 0xFFFFFFFFu, k3);
     n_box += 4;
 #ifdef PT_PAD_NODE
-    // diagnostic build only (EXPERIMENTS.md, round 4 "what bounds a trip"): PT_PAD_NODE extra independent multiplies per
-    // visit, to read the slope of frame time against VALU instructions; never compiled into the shipped library
+    // diagnostic build only (EXPERIMENTS.md, round 4 "what bounds a trip"): PT_PAD_NODE extra multiplies per visit, to
+    // read the slope of frame time against VALU instructions; never compiled into the shipped library
     {
         float pad = k0;
 #pragma unroll
@@ -1232,6 +1260,7 @@ __device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, f
     sah_begin(W, d, tmax0);
     const SahStack S = {stack, stride, P.stack_cap, nullptr, nullptr, nullptr, 0u};      // the whole stack in LDS: stack_cap is out of reach
     if (P.sah == 3) {
+        sahq_begin(W);
         while (W.n0 != 0 ? sahw_tri_step<0, true>(P, W, o, d, tmin, S, n_tri) : sahq_node_step<0, 0>(P, W, o, d, S, n_box)) {}
     } else if (P.sah == 2) {
         while (W.n0 != 0 ? sahw_tri_step<0>(P, W, o, d, tmin, S, n_tri) : sahw_node_step<0, 0>(P, W, o, d, S, n_box)) {}

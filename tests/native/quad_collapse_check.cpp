@@ -211,6 +211,95 @@ int main(int argc, char **argv)
             }
         }
     }
+    // 4. the ray parameters the device computes on the 64-byte form (quadq_ray / quadq_child_span = pt_walk.h sahq_node_eval:
+    //    slope and offset per axis, near / far byte by the sign of inv, offsets moved outwards by 2^-22):
+    //    a. against the EXACT parameters of the exact planes origin + byte * unit (128-bit arithmetic): the near one is never
+    //       above, the far one never below, by more than the half unit in the last place of the final fma -- for origins up
+    //       to a million scene extents away and slopes up to the clamp, axis-parallel rays included;
+    //    b. the walk with these parameters finds the brute-force closest hit.
+    {
+        std::uniform_real_distribution<float> P(0.0f, 1.0f);
+        const int span_rays = 4000;
+        long checked = 0;
+        for (int r = 0; r < span_rays; r++) {
+            const float far = r % 4 == 3 ? std::pow(10.0f, 6.0f * P(rng)) : 1.0f;       // every fourth origin far outside
+            float o[3] = {U(rng) * far, U(rng) * far, U(rng) * far}, d[3] = {D(rng), D(rng), D(rng)};
+            if (r % 5 == 0) d[r % 3] = (r & 8) ? 0.0f : -0.0f;                               // exactly axis-parallel
+            if (r % 7 == 0) d[(r + 1) % 3] = 1e-38f * D(rng);                               // a slope beyond the clamp
+            const QuadQ &z = qq[(size_t)(P(rng) * (float)nq) % nq];
+            if (r % 11 == 0) o[r % 3] = (&z.ox)[r % 3];                                     // the origin exactly on the grid's origin plane
+            const float inv[3] = {quadq_clamp_inv(1.0f / d[0]), quadq_clamp_inv(1.0f / d[1]), quadq_clamp_inv(1.0f / d[2])};
+            const QuadqRay R = quadq_ray(z, o, inv);
+            const float org[3] = {z.ox, z.oy, z.oz};
+            for (int c = 0; c < 4; c++) {
+                if (z.link[c] == kNone) continue;
+                const uint32_t lo[3] = {z.lo[c] & 0xffu, (z.lo[c] >> 8) & 0xffu, (z.lo[c] >> 16) & 0xffu};
+                const uint32_t hi[3] = {z.lo[c] >> 24, z.hi[c] & 0xffu, (z.hi[c] >> 8) & 0xffu};
+                for (int k = 0; k < 3; k++) {
+                    union { uint32_t u; float f; } unit; unit.u = ((z.exps >> (8 * k)) & 0xffu) << 23;
+                    const uint32_t bn = R.neg[k] ? hi[k] : lo[k], bf = R.neg[k] ? lo[k] : hi[k];
+                    const float tn = __builtin_fmaf((float)bn, R.a[k], R.near_off[k]), tf = __builtin_fmaf((float)bf, R.a[k], R.far_off[k]);
+                    const __float128 en = ((__float128)org[k] + (__float128)bn * (__float128)unit.f - (__float128)o[k]) * (__float128)inv[k];
+                    const __float128 ef = ((__float128)org[k] + (__float128)bf * (__float128)unit.f - (__float128)o[k]) * (__float128)inv[k];
+                    if (!std::isfinite(tn) || !std::isfinite(tf)) { printf("span: non-finite parameter (ray %d)\n", r); return 1; }
+                    const __float128 half_ulp = (__float128)5.9604644775390625e-08;          // 2^-24
+                    const __float128 slack_n = (en < 0 ? -en : en) * half_ulp + (__float128)1e-45, slack_f = (ef < 0 ? -ef : ef) * half_ulp + (__float128)1e-45;
+                    if ((__float128)tn > en + slack_n) { printf("span: near parameter %g above the exact %g (ray %d axis %d)\n", tn, (double)en, r, k); return 1; }
+                    if ((__float128)tf < ef - slack_f) { printf("span: far parameter %g below the exact %g (ray %d axis %d)\n", tf, (double)ef, r, k); return 1; }
+                    checked++;
+                }
+            }
+        }
+        const int qrays = n <= 20000 ? 5000 : 500;
+        std::vector<uint32_t> st(bound + 1);
+        for (int r = 0; r < qrays; r++) {
+            float o[3] = {U(rng), U(rng), U(rng)}, d[3] = {D(rng), D(rng), D(rng)};
+            if (r % 5 == 0) d[r % 3] = 0.0f;
+            const float inv[3] = {quadq_clamp_inv(1.0f / d[0]), quadq_clamp_inv(1.0f / d[1]), quadq_clamp_inv(1.0f / d[2])};
+            float t_brute = std::numeric_limits<float>::max();
+            int best_brute = -1;
+            for (size_t i = 0; i < n; i++) {
+                float t;
+                if (hit_triangle(&pos[9 * (size_t)b.order[i]], o, d, t) && t < t_brute) { t_brute = t; best_brute = (int)i; }
+            }
+            uint32_t node = 0, k0 = 0, n0 = 0;
+            int sp = 0, best = -1;
+            float tbest = std::numeric_limits<float>::max();
+            auto take = [&](uint32_t x) { if (x & 15u) { k0 = x & ~15u; n0 = x & 15u; } else node = x; };
+            auto pop = [&]() { if (sp > 0) take(st[--sp]); };
+            while (n0 != 0 || node != kNone) {
+                if (n0 != 0) {
+                    const uint32_t s = k0 / 48u;
+                    float t;
+                    if (hit_triangle(&pos[9 * (size_t)b.order[s]], o, d, t) && t < tbest) { tbest = t; best = (int)s; }
+                    k0 += 48u; n0--;
+                    if (n0 == 0 && node == kNone) pop();
+                    continue;
+                }
+                const QuadQ &z = qq[node / 64u];
+                const QuadqRay R = quadq_ray(z, o, inv);
+                float key[4];
+                uint32_t link[4];
+                for (int i = 0; i < 4; i++) {
+                    float tn, tf;
+                    quadq_child_span(z, i, R, tn, tf);
+                    key[i] = (z.link[i] != kNone && tf >= fmaxf(tn, 0.0f) && tn <= tbest) ? tn : INFINITY;
+                    link[i] = z.link[i];
+                }
+                for (int j = 1; j < 4; j++) if (key[j] < key[0]) { std::swap(key[0], key[j]); std::swap(link[0], link[j]); }
+                node = kNone;
+                for (int j = 3; j >= 1; j--) {
+                    if (!(key[j] < INFINITY)) continue;
+                    if ((uint32_t)sp >= bound) { printf("64-byte walk pushed past the bound (%u entries)\n", bound); return 1; }
+                    st[sp++] = link[j];
+                }
+                if (key[0] < INFINITY) take(link[0]); else pop();
+            }
+            const bool same = best == best_brute || (best >= 0 && best_brute >= 0 && std::fabs(tbest - t_brute) <= 1e-6f * std::fabs(t_brute));
+            if (!same) { printf("64-byte walk, ray %d: found slot %d (t %g), brute force %d (t %g)\n", r, best, tbest, best_brute, t_brute); return 1; }
+        }
+        if (checked == 0 && nq > 0 && n > 4) { printf("span check saw no plane\n"); return 1; }
+    }
     printf("ok: %zu triangles, %zu pairs -> %zu quads, stack bound %u (pair form %u), deepest in %d rays %u, %.1f visits per ray; 64-byte form adds %.2f %% to the boxes' extents\n",
            n, b.pairs.size(), nq, bound, b.max_stack, rays, deepest, visits / rays, extent > 0 ? 100.0 * slack / extent : 0.0);
     return 0;
