@@ -634,6 +634,19 @@ uint32_t sah_quads_top_levels_first(std::vector<NodePair> &quads2, uint32_t n_to
     return (uint32_t)bfs.size();
 }
 
+void sah_quads_plane_major(std::vector<NodePair> &quads2)
+{
+    for (size_t qi = 0; qi + 1 < quads2.size(); qi += 2) {
+        const NodePair h0 = quads2[qi], h1 = quads2[qi + 1];
+        const float *box[4] = {&h0.lxmin, &h0.lxmin + 6, &h1.lxmin, &h1.lxmin + 6};
+        QuadF f;
+        for (int c = 0; c < 4; c++) for (int k = 0; k < 6; k++) f.plane[k][c] = box[c][k];
+        f.link[0] = h0.llink; f.link[1] = h0.lcnt; f.link[2] = h0.rlink; f.link[3] = h0.rcnt;
+        f.pad[0] = f.pad[1] = f.pad[2] = f.pad[3] = 0u;
+        memcpy(&quads2[qi], &f, sizeof f);
+    }
+}
+
 bool quantise_sah_quads(const std::vector<NodePair> &quads2, std::vector<QuadQ> &out)
 {
     const size_t nq = quads2.size() / 2;

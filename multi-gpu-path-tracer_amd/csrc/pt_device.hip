@@ -486,6 +486,7 @@ __device__ __forceinline__ void render_sah_body(const RenderParams &P)
                     begins = true;
                     sah_begin(W, L.rd, 3.402823466e+38f);
                     if (kForm == 2) sahq_begin(W);
+                    else if (kForm == 1) sahw_begin(W);
                 }
             }
             wave_seg += (uint32_t)__builtin_popcountll(pt_ballot(begins));
@@ -570,9 +571,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel_sah(RenderParams P) { re
 // (80 VGPRs, 28 B of scratch per lane): such trees are bound by instruction issue, and with the LDS out of the way the sixth
 // wave pays for its spills (C3 107.3 -> 102.5 ms; the 64-byte-node kernel, bound by the request path, gains nothing)
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel_sahw6(RenderParams P) { render_sah_body<1, 1, 1>(P); }
-// ... and at its natural allocation (five waves, no spills) for launches of less than twice the device's wave slots, whose
+// ... and at five waves (the natural allocation is a register over: held to 96) for launches of less than twice the device's wave slots, whose
 // chains the spills lengthen (a quarter of the duck's frame: 49.0 ms against 52.1 ms with the six-wave build)
-__global__ __launch_bounds__(kBlock) void render_kernel_sahw(RenderParams P) { render_sah_body<1, 1, 1>(P); }
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_kernel_sahw(RenderParams P) { render_sah_body<1, 1, 1>(P); }
 // ... for launches with fewer tiles than the device has wave slots (a rank's share of a multi-GPU frame): nothing but the walk
 __global__ __launch_bounds__(kBlock) void render_kernel_sahw_lean(RenderParams P) { render_sah_body<1, 0, 0>(P); }
 // the 4-wide form in 64-byte records (RenderParams::sah == 3), trees beyond the caches: short LDS stack + overflow area
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel_sahw_lean(RenderParams P
 #endif
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SAHQ_WAVES, PT_SAHQ_WAVES))) void render_kernel_sahq(RenderParams P) { render_sah_body<2, 0, 1>(P); }
 // either form with both options decided per launch (PTAMD_SAH_TOP / PTAMD_SAH_STACK / PTAMD_SAH_QUANT set by hand, and the tests)
-__global__ __launch_bounds__(kBlock) void render_kernel_sahw_any(RenderParams P) { render_sah_body<1, 2, 2>(P); }
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_kernel_sahw_any(RenderParams P) { render_sah_body<1, 2, 2>(P); }
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_kernel_sahq_any(RenderParams P) { render_sah_body<2, 2, 2>(P); }
 
 // ---- known-answer kernels (bit-exactness contract) -----------------------------------
@@ -1248,6 +1249,7 @@ try {
                     sah_quant_on = true;
                 }
             }
+            if (!sah_quant_on) sah_quads_plane_major(pairs);      // the float form travels plane-major (QuadF)
         } else {
             pairs = sahbvh.pairs;
             for (NodePair &q : pairs) {

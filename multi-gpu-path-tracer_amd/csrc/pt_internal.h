@@ -144,6 +144,32 @@ inline float quadq_plane(uint32_t byte, uint32_t biased_exp, float origin)
     return __builtin_fmaf((float)byte, s.f, origin);
 }
 
+// The 4-wide form as the device reads it when the planes stay floats (RenderParams::sah == 2): plane-major, so that the row
+// of the four children's planes a ray meets FIRST on an axis is one 16-byte piece at an offset the sign of its direction
+// picks (row 2k for a rising ray, 2k + 1 for a falling one) -- the walk then needs no min / max and no select per child.
+struct QuadF {
+    float plane[6][4];            // [xlo, xhi, ylo, yhi, zlo, zhi][child]; absent children: +inf on all six
+    uint32_t link[4];             // as in the NodePair form of the quads: byte offset of a 128-byte record, or of a TriIsect | count
+    uint32_t pad[4];
+};
+static_assert(sizeof(QuadF) == 2 * sizeof(NodePair), "a QuadF record replaces the two NodePair records of a quad in place");
+void sah_quads_plane_major(std::vector<NodePair> &quads2);      // in place, after sah_quads_top_levels_first
+// The ray parameters the device computes for a QuadF child (pt_walk.h sahw_node_step): t = fma(plane, inv, offset) with
+// offset = -(o * inv) lowered (near planes) / raised (far planes) by 2^-22 of its magnitude; inv clamped as for QuadQ.
+inline void quadf_child_span(const QuadF &q, int c, const float o[3], const float inv[3], float &tn, float &tf)
+{
+    float t_near[3], t_far[3];
+    for (int k = 0; k < 3; k++) {
+        const float off = -(o[k] * inv[k]);
+        const float near_off = __builtin_fmaf(-std::fabs(off), 2.384185791015625e-07f, off), far_off = __builtin_fmaf(std::fabs(off), 2.384185791015625e-07f, off);
+        const bool neg = std::signbit(inv[k]);
+        t_near[k] = __builtin_fmaf(q.plane[2 * k + (neg ? 1 : 0)][c], inv[k], near_off);
+        t_far[k] = __builtin_fmaf(q.plane[2 * k + (neg ? 0 : 1)][c], inv[k], far_off);
+    }
+    tn = std::fmax(std::fmax(t_near[0], t_near[1]), t_near[2]);
+    tf = std::fmin(std::fmin(t_far[0], t_far[1]), t_far[2]);
+}
+
 // The ray parameters the device computes for a QuadQ child (pt_walk.h sahq_node_eval / sahq_slab), restated for the CPU
 // checks (tests/native/quad_collapse_check.cpp): per visit a slope a = unit * inv and an offset c = (origin - o) * inv per axis,
 // the offset lowered for near planes and raised for far planes by 2^-22 of its magnitude (that bounds the two roundings of c);

@@ -1061,20 +1061,6 @@ __device__ __forceinline__ bool sahw_tri_step(const RenderParams &P, SahWalk &W,
     return sah_walking(W);
 }
 
-__device__ __forceinline__ void sahw_slab(float xmin, float xmax, float ymin, float ymax, float zmin, float zmax, v3 o, v3 inv, float tbest,
-                                          float &key)
-{
-    // (Packed v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 would halve these twelve instructions and the decode's, and compile
-    // cleanly from two-element vectors -- 215 -> 173 VALU instructions per QuadQ visit -- but on gfx950 a packed f32
-    // instruction issues several times slower than the two scalar ones it replaces (MI355X_MICROARCH.md constants table;
-    // round 1's SLP measurement: C2 98 -> 118 ms), so they stay scalar.)
-    const float t1 = (xmin - o.x) * inv.x, t2 = (xmax - o.x) * inv.x, t3 = (ymin - o.y) * inv.y, t4 = (ymax - o.y) * inv.y;
-    const float t5 = (zmin - o.z) * inv.z, t6 = (zmax - o.z) * inv.z;
-    const float tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-    const float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-    const bool hit = (tf >= fmaxf(tn, 0.0f)) & (tn <= tbest);          // the test of sah_node_step, per child
-    key = hit ? tn : __builtin_inff();
-}
 __device__ __forceinline__ void sahw_order(float &ka, uint32_t &la, float &kb, uint32_t &lb)
 {
     const bool swap = kb < ka;
@@ -1082,6 +1068,37 @@ __device__ __forceinline__ void sahw_order(float &ka, uint32_t &la, float &kb, u
     const uint32_t l = swap ? lb : la; lb = swap ? la : lb; la = l;
 }
 
+// One child of a plane-major record (QuadF): its planes' ray parameters are fma(plane, inv, offset), the near planes'
+// with the lowered offset, the far planes' with the raised one (sahw_node_step).
+__device__ __forceinline__ void sahw_slab(float xn, float xf, float yn, float yf, float zn, float zf, v3 inv, float nx, float ny, float nz,
+                                          float fx, float fy, float fz, float tbest, float &key)
+{
+    // (Packed v_pk_fma_f32 would halve these and compile cleanly from two-element vectors, but on gfx950 a packed f32
+    // instruction issues several times slower than the two scalar ones it replaces (MI355X_MICROARCH.md constants table;
+    // round 1's SLP measurement: C2 98 -> 118 ms), so they stay scalar.)
+    const float t1 = fmaf(xn, inv.x, nx), t3 = fmaf(yn, inv.y, ny), t5 = fmaf(zn, inv.z, nz);
+    const float t2 = fmaf(xf, inv.x, fx), t4 = fmaf(yf, inv.y, fy), t6 = fmaf(zf, inv.z, fz);
+    const float tn = fmaxf(fmaxf(t1, t3), t5);
+    const float tf = fminf(fminf(t2, t4), t6);
+    const bool hit = (tf >= fmaxf(tn, 0.0f)) & (tn <= tbest);          // the test of sah_node_step, per child
+    key = hit ? tn : __builtin_inff();
+}
+
+// The float form's addition to sah_begin: reciprocals clamped to +-2^100, so that plane * inv is never 0 * inf for an exactly
+// axis-parallel ray (sahq_begin has the same clamp).
+__device__ __forceinline__ void sahw_begin(SahWalk &W)
+{
+    const float big = 1.2676506002282294e30f;        // 2^100
+    W.inv = mk3(fminf(fmaxf(W.inv.x, -big), big), fminf(fmaxf(W.inv.y, -big), big), fminf(fmaxf(W.inv.z, -big), big));
+}
+
+// A visit of the plane-major 128-byte record (QuadF, pt_internal.h).  The ray parameter of a plane is
+// plane * inv - o * inv: one fma per plane against an offset formed once per visit, and the row of the four children's planes
+// the ray meets first on an axis sits at an offset the sign of inv picks -- near rows and far rows are LOADED, not selected:
+// 12 instructions per child where the subtract-multiply-min-max form had 25 (150 -> 100 per visit).
+// Rounding: the offset -(o * inv) carries one rounding relative to |o * inv| that (plane - o) * inv does not have; the near
+// offsets are lowered and the far offsets raised by 2^-22 of their magnitude, which bounds it; the fma's own rounding is of
+// the kind every form has (covered, like the slab / Moller-Trumbore difference, by the builder's inflation of every box).
 // kTop: 0 = every record from memory, 1 = the tree's top levels from the workgroup's LDS copy, 2 = decided per launch
 template <int kTop, int kSpill>
 __device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, const SahStack &S, uint32_t &n_box)
@@ -1089,37 +1106,62 @@ __device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W
     uint32_t *const stack = S.lds;
     const int stride = S.stride;
     sah_stack_reserve<kSpill>(S, W, 3);
-    float4 q0, q1, q2, lk, q4, q5, q6;
+    v3 inv = W.inv;
+#ifndef PT_SAHW_HOIST
+    // (Left alone the compiler hoists everything below that depends on the ray only -- three row offsets, six plane offsets --
+    // out of the walk's loop into nine registers per lane, which the six-wave build has not got: 29 spilled registers
+    // instead of 16, C3 101.7 -> 113.3 ms.  Fifteen instructions per visit are cheaper.)
+    asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z));
+#endif
+    const uint32_t off = W.pair;
+    // byte offsets of the near / far rows: row 2k (+0) for a rising ray, 2k + 1 (+16) for a falling one; records are 128-byte aligned
+    const uint32_t xn_o = off + ((__float_as_uint(inv.x) >> 31) << 4), xf_o = xn_o ^ 16u;
+    const uint32_t yn_o = off + ((__float_as_uint(inv.y) >> 31) << 4), yf_o = yn_o ^ 16u;
+    const uint32_t zn_o = off + ((__float_as_uint(inv.z) >> 31) << 4), zf_o = zn_o ^ 16u;
+    float4 xn, xf, yn, yf, zn, zf, lk;
     if (kTop == 0 || (kTop == 2 && S.top_bytes == 0u)) {
-        const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P.nodes) + (size_t)W.pair);
-        q0 = np[0]; q1 = np[1]; q2 = np[2]; lk = np[3]; q4 = np[4]; q5 = np[5]; q6 = np[6];
+        const char *base = reinterpret_cast<const char *>(P.nodes);
+        xn = *reinterpret_cast<const float4 *>(base + (size_t)xn_o); xf = *reinterpret_cast<const float4 *>(base + (size_t)xf_o);
+        yn = *reinterpret_cast<const float4 *>(base + (size_t)yn_o + 32); yf = *reinterpret_cast<const float4 *>(base + (size_t)yf_o + 32);
+        zn = *reinterpret_cast<const float4 *>(base + (size_t)zn_o + 64); zf = *reinterpret_cast<const float4 *>(base + (size_t)zf_o + 64);
+        lk = *reinterpret_cast<const float4 *>(base + (size_t)off + 96);
     } else {
         // A lane's record comes from the workgroup's LDS copy of the top levels or from memory.  Written as a select per float4
         // (`in_top ? lds[k] : global[k]`) the compiler selects the POINTER and fetches through seven flat_load_dwordx4 -- every
-        // request then goes down both the LDS and the vector-memory path and is waited for on both counters (and the first two
-        // were waited for before the other five were issued).  Two address spaces, two exec-masked groups of loads, one wait:
+        // request then goes down both the LDS and the vector-memory path and is waited for on both counters.  Two address
+        // spaces, two exec-masked groups of loads, one wait:
         typedef const __attribute__((address_space(3))) pt_f4 *LdsF4Ptr;
         typedef const __attribute__((address_space(1))) pt_f4 *GlobalF4Ptr;
-        const uint32_t off = W.pair;
+        typedef const __attribute__((address_space(3))) char *LdsBytePtr;
+        typedef const __attribute__((address_space(1))) char *GlobalBytePtr;
         const bool in_top = off < S.top_bytes;
         pt_f4 r0, r1, r2, r3, r4, r5, r6;
         if (!in_top) {
-            GlobalF4Ptr g = (GlobalF4Ptr)(reinterpret_cast<const char *>(P.nodes) + (size_t)off);
-            r0 = g[0]; r1 = g[1]; r2 = g[2]; r3 = g[3]; r4 = g[4]; r5 = g[5]; r6 = g[6];
+            GlobalBytePtr g = (GlobalBytePtr)(reinterpret_cast<const char *>(P.nodes));
+            r0 = *(GlobalF4Ptr)(g + (size_t)xn_o); r1 = *(GlobalF4Ptr)(g + (size_t)xf_o);
+            r2 = *(GlobalF4Ptr)(g + (size_t)yn_o + 32); r3 = *(GlobalF4Ptr)(g + (size_t)yf_o + 32);
+            r4 = *(GlobalF4Ptr)(g + (size_t)zn_o + 64); r5 = *(GlobalF4Ptr)(g + (size_t)zf_o + 64);
+            r6 = *(GlobalF4Ptr)(g + (size_t)off + 96);
         } else {
-            LdsF4Ptr t = (LdsF4Ptr)(S.top) + off / 16u;
-            r0 = t[0]; r1 = t[1]; r2 = t[2]; r3 = t[3]; r4 = t[4]; r5 = t[5]; r6 = t[6];
+            LdsBytePtr t = (LdsBytePtr)(S.top);
+            r0 = *(LdsF4Ptr)(t + xn_o); r1 = *(LdsF4Ptr)(t + xf_o);
+            r2 = *(LdsF4Ptr)(t + yn_o + 32); r3 = *(LdsF4Ptr)(t + yf_o + 32);
+            r4 = *(LdsF4Ptr)(t + zn_o + 64); r5 = *(LdsF4Ptr)(t + zf_o + 64);
+            r6 = *(LdsF4Ptr)(t + off + 96);
         }
-        q0 = make_float4(r0.x, r0.y, r0.z, r0.w); q1 = make_float4(r1.x, r1.y, r1.z, r1.w); q2 = make_float4(r2.x, r2.y, r2.z, r2.w);
-        lk = make_float4(r3.x, r3.y, r3.z, r3.w); q4 = make_float4(r4.x, r4.y, r4.z, r4.w); q5 = make_float4(r5.x, r5.y, r5.z, r5.w);
-        q6 = make_float4(r6.x, r6.y, r6.z, r6.w);
+        xn = make_float4(r0.x, r0.y, r0.z, r0.w); xf = make_float4(r1.x, r1.y, r1.z, r1.w); yn = make_float4(r2.x, r2.y, r2.z, r2.w);
+        yf = make_float4(r3.x, r3.y, r3.z, r3.w); zn = make_float4(r4.x, r4.y, r4.z, r4.w); zf = make_float4(r5.x, r5.y, r5.z, r5.w);
+        lk = make_float4(r6.x, r6.y, r6.z, r6.w);
     }
-    const v3 inv = W.inv;
+    const float cx = -(o.x * inv.x), cy = -(o.y * inv.y), cz = -(o.z * inv.z);
+    const float m = 2.384185791015625e-07f;          // 2^-22
+    const float nx = fmaf(-fabsf(cx), m, cx), ny = fmaf(-fabsf(cy), m, cy), nz = fmaf(-fabsf(cz), m, cz);
+    const float fx = fmaf(fabsf(cx), m, cx), fy = fmaf(fabsf(cy), m, cy), fz = fmaf(fabsf(cz), m, cz);
     float k0, k1, k2, k3;
-    sahw_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, W.tbest, k0);
-    sahw_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, W.tbest, k1);
-    sahw_slab(q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, o, inv, W.tbest, k2);
-    sahw_slab(q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, o, inv, W.tbest, k3);
+    sahw_slab(xn.x, xf.x, yn.x, yf.x, zn.x, zf.x, inv, nx, ny, nz, fx, fy, fz, W.tbest, k0);
+    sahw_slab(xn.y, xf.y, yn.y, yf.y, zn.y, zf.y, inv, nx, ny, nz, fx, fy, fz, W.tbest, k1);
+    sahw_slab(xn.z, xf.z, yn.z, yf.z, zn.z, zf.z, inv, nx, ny, nz, fx, fy, fz, W.tbest, k2);
+    sahw_slab(xn.w, xf.w, yn.w, yf.w, zn.w, zf.w, inv, nx, ny, nz, fx, fy, fz, W.tbest, k3);
     uint32_t l0 = __float_as_uint(lk.x), l1 = __float_as_uint(lk.y), l2 = __float_as_uint(lk.z), l3 = __float_as_uint(lk.w);
     n_box += 4;
     // The nearest child to be entered goes first; the others wait in whatever order they end up in.  A full sort (five
@@ -1263,6 +1305,7 @@ __device__ __forceinline__ Hit traverse_sah(const RenderParams &P, v3 o, v3 d, f
         sahq_begin(W);
         while (W.n0 != 0 ? sahw_tri_step<0, true>(P, W, o, d, tmin, S, n_tri) : sahq_node_step<0, 0>(P, W, o, d, S, n_box)) {}
     } else if (P.sah == 2) {
+        sahw_begin(W);
         while (W.n0 != 0 ? sahw_tri_step<0>(P, W, o, d, tmin, S, n_tri) : sahw_node_step<0, 0>(P, W, o, d, S, n_box)) {}
     } else {
         while (sah_step(P, W, o, d, tmin, S, n_box, n_tri)) {}

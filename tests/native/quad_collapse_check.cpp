@@ -300,6 +300,98 @@ int main(int argc, char **argv)
         }
         if (checked == 0 && nq > 0 && n > 4) { printf("span check saw no plane\n"); return 1; }
     }
+    // 5. the plane-major float form (sah_quads_plane_major / quadf_child_span = pt_walk.h sahw_node_step): same links, the
+    //    planes transposed; its ray parameters bracket the exact (plane - o) * inv of every plane like the 64-byte form's, and
+    //    the walk with them finds the brute-force closest hit.
+    {
+        std::vector<NodePair> pm = q;
+        sah_quads_plane_major(pm);
+        const QuadF *F = reinterpret_cast<const QuadF *>(pm.data());
+        for (size_t qi = 0; qi < nq; qi++) {
+            const Quad Q = quad_at(q, (uint32_t)qi);
+            for (int c = 0; c < 4; c++) {
+                if (F[qi].link[c] != Q.link[c]) { printf("plane-major: quad %zu child %d link changed\n", qi, c); return 1; }
+                for (int k = 0; k < 6; k++) if (!(F[qi].plane[k][c] == Q.box[c][k])) { printf("plane-major: quad %zu child %d plane %d changed\n", qi, c, k); return 1; }
+            }
+        }
+        std::uniform_real_distribution<float> P(0.0f, 1.0f);
+        for (int r = 0; r < 4000; r++) {
+            const float far = r % 4 == 3 ? std::pow(10.0f, 6.0f * P(rng)) : 1.0f;
+            float o[3] = {U(rng) * far, U(rng) * far, U(rng) * far}, d[3] = {D(rng), D(rng), D(rng)};
+            if (r % 5 == 0) d[r % 3] = (r & 8) ? 0.0f : -0.0f;
+            if (r % 7 == 0) d[(r + 1) % 3] = 1e-38f * D(rng);
+            const QuadF &z = F[(size_t)(P(rng) * (float)nq) % nq];
+            if (r % 11 == 0) o[r % 3] = z.plane[2 * (r % 3)][0] < INFINITY ? z.plane[2 * (r % 3)][0] : 0.0f;      // the origin exactly on a plane
+            const float inv[3] = {quadq_clamp_inv(1.0f / d[0]), quadq_clamp_inv(1.0f / d[1]), quadq_clamp_inv(1.0f / d[2])};
+            for (int c = 0; c < 4; c++) {
+                if (!(z.plane[0][c] < INFINITY)) {
+                    float tn, tf;
+                    quadf_child_span(z, c, o, inv, tn, tf);
+                    if (tf >= fmaxf(tn, 0.0f) && tn <= std::numeric_limits<float>::max()) { printf("plane-major: an absent child was accepted\n"); return 1; }
+                    continue;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const float off = -(o[k] * inv[k]);
+                    const float near_off = __builtin_fmaf(-std::fabs(off), 2.384185791015625e-07f, off), far_off = __builtin_fmaf(std::fabs(off), 2.384185791015625e-07f, off);
+                    const bool neg = std::signbit(inv[k]);
+                    const float pn = z.plane[2 * k + (neg ? 1 : 0)][c], pf = z.plane[2 * k + (neg ? 0 : 1)][c];
+                    const float tn = __builtin_fmaf(pn, inv[k], near_off), tf = __builtin_fmaf(pf, inv[k], far_off);
+                    const __float128 en = ((__float128)pn - (__float128)o[k]) * (__float128)inv[k], ef = ((__float128)pf - (__float128)o[k]) * (__float128)inv[k];
+                    const __float128 half_ulp = (__float128)5.9604644775390625e-08;
+                    if (!std::isfinite(tn) || !std::isfinite(tf)) { printf("plane-major span: non-finite parameter (ray %d)\n", r); return 1; }
+                    if ((__float128)tn > en + (en < 0 ? -en : en) * half_ulp + (__float128)1e-45) { printf("plane-major span: near parameter %g above the exact %g (ray %d axis %d)\n", tn, (double)en, r, k); return 1; }
+                    if ((__float128)tf < ef - (ef < 0 ? -ef : ef) * half_ulp - (__float128)1e-45) { printf("plane-major span: far parameter %g below the exact %g (ray %d axis %d)\n", tf, (double)ef, r, k); return 1; }
+                }
+            }
+        }
+        const int frays = n <= 20000 ? 5000 : 500;
+        std::vector<uint32_t> st(bound + 1);
+        for (int r = 0; r < frays; r++) {
+            float o[3] = {U(rng), U(rng), U(rng)}, d[3] = {D(rng), D(rng), D(rng)};
+            if (r % 5 == 0) d[r % 3] = 0.0f;
+            const float inv[3] = {quadq_clamp_inv(1.0f / d[0]), quadq_clamp_inv(1.0f / d[1]), quadq_clamp_inv(1.0f / d[2])};
+            float t_brute = std::numeric_limits<float>::max();
+            int best_brute = -1;
+            for (size_t i = 0; i < n; i++) {
+                float t;
+                if (hit_triangle(&pos[9 * (size_t)b.order[i]], o, d, t) && t < t_brute) { t_brute = t; best_brute = (int)i; }
+            }
+            uint32_t node = 0, k0 = 0, n0 = 0;
+            int sp = 0, best = -1;
+            float tbest = std::numeric_limits<float>::max();
+            auto take = [&](uint32_t x) { if (x & 15u) { k0 = x & ~15u; n0 = x & 15u; } else node = x; };
+            auto pop = [&]() { if (sp > 0) take(st[--sp]); };
+            while (n0 != 0 || node != kNone) {
+                if (n0 != 0) {
+                    const uint32_t s = k0 / 48u;
+                    float t;
+                    if (hit_triangle(&pos[9 * (size_t)b.order[s]], o, d, t) && t < tbest) { tbest = t; best = (int)s; }
+                    k0 += 48u; n0--;
+                    if (n0 == 0 && node == kNone) pop();
+                    continue;
+                }
+                const QuadF &z = F[node / 128u];
+                float key[4];
+                uint32_t link[4];
+                for (int i = 0; i < 4; i++) {
+                    float tn, tf;
+                    quadf_child_span(z, i, o, inv, tn, tf);
+                    key[i] = (tf >= fmaxf(tn, 0.0f) && tn <= tbest) ? tn : INFINITY;
+                    link[i] = z.link[i];
+                }
+                for (int j = 1; j < 4; j++) if (key[j] < key[0]) { std::swap(key[0], key[j]); std::swap(link[0], link[j]); }
+                node = kNone;
+                for (int j = 3; j >= 1; j--) {
+                    if (!(key[j] < INFINITY)) continue;
+                    if ((uint32_t)sp >= bound) { printf("plane-major walk pushed past the bound (%u entries)\n", bound); return 1; }
+                    st[sp++] = link[j];
+                }
+                if (key[0] < INFINITY) take(link[0]); else pop();
+            }
+            const bool same = best == best_brute || (best >= 0 && best_brute >= 0 && std::fabs(tbest - t_brute) <= 1e-6f * std::fabs(t_brute));
+            if (!same) { printf("plane-major walk, ray %d: found slot %d (t %g), brute force %d (t %g)\n", r, best, tbest, best_brute, t_brute); return 1; }
+        }
+    }
     printf("ok: %zu triangles, %zu pairs -> %zu quads, stack bound %u (pair form %u), deepest in %d rays %u, %.1f visits per ray; 64-byte form adds %.2f %% to the boxes' extents\n",
            n, b.pairs.size(), nq, bound, b.max_stack, rays, deepest, visits / rays, extent > 0 ? 100.0 * slack / extent : 0.0);
     return 0;
