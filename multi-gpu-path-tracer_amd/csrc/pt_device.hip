@@ -577,8 +577,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) 
 // ... for launches with fewer tiles than the device has wave slots (a rank's share of a multi-GPU frame): nothing but the walk
 __global__ __launch_bounds__(kBlock) void render_kernel_sahw_lean(RenderParams P) { render_sah_body<1, 0, 0>(P); }
 // the 4-wide form in 64-byte records (RenderParams::sah == 3), trees beyond the caches: short LDS stack + overflow area
-// (five waves per SIMD asked for: with both records of a triangle pair in flight at once the natural allocation is 100 VGPRs,
-// one too many registers' worth for the fifth wave; held to 96 it spills one)
+// (five waves per SIMD asked for: with both records of a triangle pair in flight at once the allocation sits at the fifth
+// wave's limit of 96 VGPRs; a sixth wave -- 80 VGPRs, 16 spilled -- loses: C4 47.6 -> 49.4 ms)
 #ifndef PT_SAHQ_WAVES
 #define PT_SAHQ_WAVES 5
 #endif
@@ -1235,10 +1235,10 @@ try {
             sah_top_moved = dev->sah_top > 0 ? sah_quads_top_levels_first(pairs, (uint32_t)dev->sah_top) : 0u;
             // Trees that do not fit the caches take the 4-wide form at half the bytes (QuadQ: 8-bit child planes, rounded
             // outwards): a visit is four per-lane 16-byte requests instead of seven, and on the 8.4 M-triangle terrain the
-            // vector-memory path was 70 % busy serving them (profiles/r03_sah_lane_census.json).  The decode costs ~48
-            // instructions per visit.  With the short LDS stack's fifth workgroup per CU: C4 55.4 -> 51.7 ms.  Cache-resident
-            // trees keep the 128-byte form: with their top levels in LDS (below) it is the faster one there (C3 110 ms against
-            // 120 ms for the 64-byte form; the Cornell box through the SAH tree 74 against 79 ms).
+            // vector-memory path was 70 % busy serving them (profiles/r03_sah_lane_census.json).  A visit is 144
+            // VALU instructions (byte -> ray parameter by one conversion and one fma, pt_walk.h sahq_node_eval) against 100 for the
+            // float planes.  Cache-resident trees keep the 128-byte form (plane-major, below): with their top levels in LDS it is
+            // the faster one there (C3 100.8 ms against 108.1 ms for the 64-byte form, profiles/r04_c4_visit_slope.json).
             const size_t wide_bytes = pairs.size() * sizeof(NodePair) + n * sizeof(TriIsect);
             if (dev->sah_quant == 1 || (dev->sah_quant < 0 && wide_bytes > ((size_t)64 << 20))) {
                 std::vector<QuadQ> qq;

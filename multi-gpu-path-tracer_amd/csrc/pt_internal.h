@@ -107,6 +107,7 @@ void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out, uint32_t
 // from a pair by replacing its larger inner children with their own two children.  128 B = two NodePair-sized halves:
 // floats [0..11] the boxes of children 0 and 1 (x/y/z min, max each, as in NodePair), [12..23] children 2 and 3 (second
 // half's floats [0..11]), links in the FIRST half's link words [12..15]; the second half's link words are unused.
+// (That is the builder's and the checks' form; the device reads it transposed: QuadF / sah_quads_plane_major below.)
 // A link is a BYTE offset: of a QuadNode (multiple of 128: low four bits zero), or of a leaf's first TriIsect record
 // (multiple of 48, so of 16) with the leaf's triangle count (1..15) in the low four bits.  An absent child has an inverted
 // box and is never hit.  Returns false when the tree cannot take this form (a leaf of more than 15 triangles, which the
@@ -123,7 +124,8 @@ uint32_t sah_quads_top_levels_first(std::vector<NodePair> &quads2, uint32_t n_to
 // instead of seven.  The four child boxes are 8-bit offsets from the node's origin in power-of-two units per axis:
 //   plane = fmaf((float)byte, 2^e_axis, origin_axis)
 // and quantise_sah_quads rounds every low plane DOWN and every high plane UP against exactly that expression, so a
-// decoded box always contains the box it stands for: the walk may enter a subtree it could have skipped (+ <1 % triangle
+// decoded box always contains the box it stands for (and the device brackets the decoded planes' exact ray parameters from
+// outside, quadq_ray below; tests/native/quad_collapse_check.cpp checks both steps): the walk may enter a subtree it could have skipped (+ <1 % triangle
 // tests), never the other way round, and the closest hit -- min over (t, rank) of the triangles tested -- cannot change.
 struct QuadQ {
     float ox, oy, oz;             // origin: the per-axis minimum over the node's children

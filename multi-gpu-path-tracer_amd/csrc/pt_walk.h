@@ -1183,8 +1183,9 @@ __device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W
 // origin + byte * unit (unit a power of two), so its ray parameter is byte * (unit * inv) + (origin - o) * inv: per visit
 // three slopes and three offsets, per plane one conversion and one fma.  Which of a child's two planes per axis the ray meets
 // first is the sign of inv, the same for every node: v_perm_b32 gathers the three near bytes and the three far bytes (W.sel),
-// which replaces the six min / max of the symmetric slab test.  Round 4 measured the slope: 0.09 ms of a C4 frame per VALU
-// instruction of a visit (profiles/r04_c4_visit_slope.json); this form has 140 where the decode-then-slab form had 193.
+// which replaces the six min / max of the symmetric slab test: 144 VALU instructions per visit where the decode-then-slab
+// form had 193, C4 47.5 -> 46.0 ms (profiles/r04_c4_visit_slope.json: a visit's instructions and requests both sit at a knee --
+// 24 padded multiplies cost 2.3 ms, one padded request 2.0 ms, two 8.7 ms -- so what is removed on one side pays in part).
 // Rounding.  Against the exact parameter of the decoded plane the offset carries two roundings relative to |origin - o|
 // (the subtraction, the product), which the unfolded form did not have: the near offsets are lowered and the far offsets
 // raised by 2^-22 of their magnitude, which bounds both; the last rounding (the fma's, relative to t itself) is of the
