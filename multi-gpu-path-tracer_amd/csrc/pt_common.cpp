@@ -99,7 +99,7 @@ try {
             pos[9 * i + 6 + k] = tris[i].v2.position[k];
         }
     SahBvh bvh;
-    build_sah_bvh(pos.data(), n, bvh);
+    build_sah_bvh(pos.data(), n, bvh, sah_leaf_size_for(n));
     if (info) {
         info->nodes = (uint32_t)bvh.pairs.size(); info->leaves = 0; info->max_leaf = bvh.max_leaf; info->depth = bvh.max_stack;
         info->max_stack = bvh.max_stack; info->lights = 0; info->triangles = (uint32_t)n;

@@ -1160,7 +1160,9 @@ try {
     bool sah_wide_on = false, sah_quant_on = false;
     uint32_t sah_top_moved = 0;
     if (sah) {
-        build_sah_bvh(pos.data(), n, sahbvh);
+        uint32_t max_leaf = sah_leaf_size_for(n);
+        if (const char *e = getenv("PTAMD_SAH_LEAF")) { const int v = atoi(e); if (v >= 1 && v <= 15) max_leaf = (uint32_t)v; }
+        build_sah_bvh(pos.data(), n, sahbvh, max_leaf);
         if (sahbvh.max_stack > 64) return set_error(PT_ERR_STACK, "SAH tree deeper than 64 levels");
     }
 
