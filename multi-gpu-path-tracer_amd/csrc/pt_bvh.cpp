@@ -449,11 +449,17 @@ void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out, uint32_t
     SahBuilder b(tris, max_leaf < 1 ? 1u : max_leaf);
     b.nodes.reserve(n_tris);
     int root = b.build(0, (uint32_t)n_tris, 0);
-    // epsilon: absolute part from the scene extent, relative part from the coordinate magnitude
-    float ext = std::max(smx[0] - smn[0], std::max(smx[1] - smn[1], smx[2] - smn[2]));
+    // The inflation that keeps pruning conservative against the Moller-Trumbore arithmetic: a ray the float test accepts passes
+    // the exact triangle within a few units in the last place of the coordinates involved (the test's products carry ~3 roundings
+    // relative to |o - v0|; for a grazing ray the in-plane error grows by 1 / cos but the perpendicular miss does not), so the
+    // boxes grow by 1e-5 of the largest coordinate magnitude (~170 ulps; mag >= extent / 2) + 1e-6.  Rounds 1-3 also added 1e-4
+    // of the scene's EXTENT -- 0.11 on the 1000-wide terrain whose cells are 0.49 wide: every leaf box 45 % wider per axis, 11.0
+    // triangle tests per segment where 6.1 do (C4 45.8 -> 34.6 ms).  The f-1 gates (1e7 rays x {box, duck}, 1e6 + brute force on the
+    // 8.4 M-triangle terrain) still pass at 1e-7 of the magnitude and fail at 1e-8 (profiles/r04_c4_visit_slope.json).  Origins far
+    // outside the scene are the walk's business: its offsets' margin grows with |origin - o| (pt_walk.h sahq_node_eval).
     float mag = 0.0f;
     for (int k = 0; k < 3; k++) mag = std::max(mag, std::max(fabsf(smn[k]), fabsf(smx[k])));
-    const float eps = 1e-4f * ext + 1e-5f * mag + 1e-6f;
+    const float eps = 1e-5f * mag + 1e-6f;
     // flatten inner nodes to NodePair records in DFS pre-order; a leaf root becomes a pair whose
     // right child is an empty (inverted) box
     std::vector<int> pair_of(b.nodes.size(), -1);

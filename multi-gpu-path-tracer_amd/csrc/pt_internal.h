@@ -162,13 +162,13 @@ struct QuadF {
 static_assert(sizeof(QuadF) == 2 * sizeof(NodePair), "a QuadF record replaces the two NodePair records of a quad in place");
 void sah_quads_plane_major(std::vector<NodePair> &quads2);      // in place, after sah_quads_top_levels_first
 // The ray parameters the device computes for a QuadF child (pt_walk.h sahw_node_step): t = fma(plane, inv, offset) with
-// offset = -(o * inv) lowered (near planes) / raised (far planes) by 2^-22 of its magnitude; inv clamped as for QuadQ.
+// offset = -(o * inv) lowered (near planes) / raised (far planes) by 2^-19 of its magnitude; inv clamped as for QuadQ.
 inline void quadf_child_span(const QuadF &q, int c, const float o[3], const float inv[3], float &tn, float &tf)
 {
     float t_near[3], t_far[3];
     for (int k = 0; k < 3; k++) {
         const float off = -(o[k] * inv[k]);
-        const float near_off = __builtin_fmaf(-std::fabs(off), 2.384185791015625e-07f, off), far_off = __builtin_fmaf(std::fabs(off), 2.384185791015625e-07f, off);
+        const float near_off = __builtin_fmaf(-std::fabs(off), 1.9073486328125e-06f, off), far_off = __builtin_fmaf(std::fabs(off), 1.9073486328125e-06f, off);
         const bool neg = std::signbit(inv[k]);
         t_near[k] = __builtin_fmaf(q.plane[2 * k + (neg ? 1 : 0)][c], inv[k], near_off);
         t_far[k] = __builtin_fmaf(q.plane[2 * k + (neg ? 0 : 1)][c], inv[k], far_off);
@@ -179,7 +179,7 @@ inline void quadf_child_span(const QuadF &q, int c, const float o[3], const floa
 
 // The ray parameters the device computes for a QuadQ child (pt_walk.h sahq_node_eval / sahq_slab), restated for the CPU
 // checks (tests/native/quad_collapse_check.cpp): per visit a slope a = unit * inv and an offset c = (origin - o) * inv per axis,
-// the offset lowered for near planes and raised for far planes by 2^-22 of its magnitude (that bounds the two roundings of c);
+// the offset lowered for near planes and raised for far planes by 2^-19 of its magnitude (that bounds the two roundings of c);
 // per plane t = fma(byte, a, offset).  inv must be clamped to +-2^100 (sahq_begin).
 struct QuadqRay { float a[3], near_off[3], far_off[3]; bool neg[3]; };
 inline float quadq_clamp_inv(float inv) { const float big = 1.2676506002282294e30f; return std::fmin(std::fmax(inv, -big), big); }
@@ -191,8 +191,8 @@ inline QuadqRay quadq_ray(const QuadQ &q, const float o[3], const float inv[3])
         union { uint32_t u; float f; } unit; unit.u = ((q.exps >> (8 * k)) & 0xffu) << 23;
         r.a[k] = unit.f * inv[k];
         const float c = (org[k] - o[k]) * inv[k];
-        r.near_off[k] = __builtin_fmaf(-std::fabs(c), 2.384185791015625e-07f, c);
-        r.far_off[k] = __builtin_fmaf(std::fabs(c), 2.384185791015625e-07f, c);
+        r.near_off[k] = __builtin_fmaf(-std::fabs(c), 1.9073486328125e-06f, c);
+        r.far_off[k] = __builtin_fmaf(std::fabs(c), 1.9073486328125e-06f, c);
         r.neg[k] = std::signbit(inv[k]);
     }
     return r;

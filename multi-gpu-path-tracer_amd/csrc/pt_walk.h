@@ -1097,8 +1097,10 @@ __device__ __forceinline__ void sahw_begin(SahWalk &W)
 // the ray meets first on an axis sits at an offset the sign of inv picks -- near rows and far rows are LOADED, not selected:
 // 12 instructions per child where the subtract-multiply-min-max form had 25 (150 -> 100 per visit).
 // Rounding: the offset -(o * inv) carries one rounding relative to |o * inv| that (plane - o) * inv does not have; the near
-// offsets are lowered and the far offsets raised by 2^-22 of their magnitude, which bounds it; the fma's own rounding is of
-// the kind every form has (covered, like the slab / Moller-Trumbore difference, by the builder's inflation of every box).
+// offsets are lowered and the far offsets raised by 2^-19 of their magnitude: 2^-23 bounds that rounding, the rest widens every
+// box by 2e-6 |o| -- the share of the slab / Moller-Trumbore difference that grows with the origin's distance, which the
+// builder's inflation (1e-5 of the scene's coordinate magnitude, pt_bvh.cpp) cannot know; the fma's own rounding is of the
+// kind every form has and is inside that inflation.
 // kTop: 0 = every record from memory, 1 = the tree's top levels from the workgroup's LDS copy, 2 = decided per launch
 template <int kTop, int kSpill>
 __device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W, v3 o, v3 d, const SahStack &S, uint32_t &n_box)
@@ -1154,7 +1156,7 @@ __device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W
         lk = make_float4(r6.x, r6.y, r6.z, r6.w);
     }
     const float cx = -(o.x * inv.x), cy = -(o.y * inv.y), cz = -(o.z * inv.z);
-    const float m = 2.384185791015625e-07f;          // 2^-22
+    const float m = 1.9073486328125e-06f;          // 2^-19
     const float nx = fmaf(-fabsf(cx), m, cx), ny = fmaf(-fabsf(cy), m, cy), nz = fmaf(-fabsf(cz), m, cz);
     const float fx = fmaf(fabsf(cx), m, cx), fy = fmaf(fabsf(cy), m, cy), fz = fmaf(fabsf(cz), m, cz);
     float k0, k1, k2, k3;
@@ -1188,9 +1190,10 @@ __device__ __forceinline__ bool sahw_node_step(const RenderParams &P, SahWalk &W
 // 24 padded multiplies cost 2.3 ms, one padded request 2.0 ms, two 8.7 ms -- so what is removed on one side pays in part).
 // Rounding.  Against the exact parameter of the decoded plane the offset carries two roundings relative to |origin - o|
 // (the subtraction, the product), which the unfolded form did not have: the near offsets are lowered and the far offsets
-// raised by 2^-22 of their magnitude, which bounds both; the last rounding (the fma's, relative to t itself) is of the
-// kind every form has and is covered, like the difference between slab and Moller-Trumbore arithmetic, by the builder's
-// inflation of every box (pt_bvh.cpp: 1e-4 of the scene's extent + 1e-5 of its coordinates' magnitude).
+// raised by 2^-19 of their magnitude: 2^-22 bounds both, the rest widens every box by 2e-6 |origin - o| -- the share of the
+// difference between slab and Moller-Trumbore arithmetic that grows with the origin's distance (the test's products round
+// relative to |o - v0|), which the builder's inflation of every box (pt_bvh.cpp: 1e-5 of the scene's coordinate magnitude)
+// cannot know.  The last rounding (the fma's, relative to t itself) is of the kind every form has and is inside that inflation.
 __device__ __forceinline__ void sahq_slab(uint32_t lo, uint32_t hi, uint32_t sel_n, uint32_t sel_f, float ax, float ay, float az,
                                           float nx, float ny, float nz, float fx, float fy, float fz, float tbest, bool present, float &key)
 {
@@ -1214,7 +1217,7 @@ __device__ __forceinline__ void sahq_node_eval(SahWalk &W, v3 o, const SahStack 
     const v3 inv = W.inv;
     const float ax = sx * inv.x, ay = sy * inv.y, az = sz * inv.z;
     const float cx = (q0.x - o.x) * inv.x, cy = (q0.y - o.y) * inv.y, cz = (q0.z - o.z) * inv.z;
-    const float m = 2.384185791015625e-07f;          // 2^-22
+    const float m = 1.9073486328125e-06f;          // 2^-19
     const float nx = fmaf(-fabsf(cx), m, cx), ny = fmaf(-fabsf(cy), m, cy), nz = fmaf(-fabsf(cz), m, cz);
     const float fx = fmaf(fabsf(cx), m, cx), fy = fmaf(fabsf(cy), m, cy), fz = fmaf(fabsf(cz), m, cz);
     const uint32_t sel_n = W.sel, sel_f = W.sel ^ kSahqFarXor;

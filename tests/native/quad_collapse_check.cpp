@@ -212,7 +212,7 @@ int main(int argc, char **argv)
         }
     }
     // 4. the ray parameters the device computes on the 64-byte form (quadq_ray / quadq_child_span = pt_walk.h sahq_node_eval:
-    //    slope and offset per axis, near / far byte by the sign of inv, offsets moved outwards by 2^-22):
+    //    slope and offset per axis, near / far byte by the sign of inv, offsets moved outwards by 2^-19):
     //    a. against the EXACT parameters of the exact planes origin + byte * unit (128-bit arithmetic): the near one is never
     //       above, the far one never below, by more than the half unit in the last place of the final fma -- for origins up
     //       to a million scene extents away and slopes up to the clamp, axis-parallel rays included;
@@ -332,7 +332,7 @@ int main(int argc, char **argv)
                 }
                 for (int k = 0; k < 3; k++) {
                     const float off = -(o[k] * inv[k]);
-                    const float near_off = __builtin_fmaf(-std::fabs(off), 2.384185791015625e-07f, off), far_off = __builtin_fmaf(std::fabs(off), 2.384185791015625e-07f, off);
+                    const float near_off = __builtin_fmaf(-std::fabs(off), 1.9073486328125e-06f, off), far_off = __builtin_fmaf(std::fabs(off), 1.9073486328125e-06f, off);
                     const bool neg = std::signbit(inv[k]);
                     const float pn = z.plane[2 * k + (neg ? 1 : 0)][c], pf = z.plane[2 * k + (neg ? 0 : 1)][c];
                     const float tn = __builtin_fmaf(pn, inv[k], near_off), tf = __builtin_fmaf(pf, inv[k], far_off);
