@@ -773,7 +773,7 @@ __device__ __forceinline__ Hit traverse_uniform_stack_dealt(const RenderParams &
 // closest hit is min over (t, rank) -- rank = the triangle's position in the reference's visit
 // order -- which is what the reference's in-order `t < ray_t.max` update computes over the
 // triangles it tests.  Differences from the reference are confined to rays for which the two
-// traversals test different triangles AND such a triangle wins (DESIGN.md section 4b).
+// traversals test different triangles AND such a triangle wins (DESIGN.md section 1, row f-1).
 // Records of the SAH tree are addressed by 32-bit BYTE OFFSETS from the array bases (pt_upload_scene scales the
 // builder's links: pair index x 64, leaf-order slot x 48; both arrays stay far below 4 GB): a record's address is then
 // "uniform base + per-lane 32-bit offset", which a global load takes as it is, instead of a 64-bit multiply-add per step.

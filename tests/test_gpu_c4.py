@@ -156,7 +156,18 @@ def test_c4_scale_closest_hit_gate(pt, ob, terrain, gpu_device):
     hits = int((f_ref >= 0).sum())
     print("C4-scale gate (%s): %d of %d rays differ between the SAH walk (%.1f s) and the reference-topology walk (%.1f s); %d hit"
           % (form, int((~same).sum()), n, t_sah_s, t_ref_s, hits))
-    assert int((~same).sum()) == 0
+    diff = np.nonzero(~same)[0]
+    if len(diff):
+        # One class of ray may differ (1 of 1e7 rays here, none of the default 1e6): a ray that lies EXACTLY in a
+        # face of one of the reference's boxes -- a direction component of exactly 0 and the origin's coordinate on the plane --
+        # for which the reference's own aabb::hit computes 0 * inf = NaN and drops the box with the triangle in it.  There the
+        # SAH walk must equal the brute force over ALL triangles with the oracle's triangle test, the reference walk must not.
+        t_d, f_d, ties_d = ob.brute_closest(terrain.triangles, org[diff], dirs[diff], threads=min(16, os.cpu_count() or 1))
+        in_plane = (dirs[diff] == 0.0).any(axis=1)
+        sah_is_brute = (t_sah[diff].view(np.uint32) == t_d.view(np.uint32)) & ((f_sah[diff] == f_d) | (ties_d > 1))
+        print("   %d differing rays: %d with a direction component of exactly 0, %d where the SAH walk equals the brute force"
+              % (len(diff), int(in_plane.sum()), int(sah_is_brute.sum())))
+        assert in_plane.all() and sah_is_brute.all() and len(diff) * 1_000_000 <= n
     assert hits > n // 3
     t0 = time.perf_counter()
     t_b, f_b, ties = ob.brute_closest(terrain.triangles, org[:n_brute], dirs[:n_brute], threads=min(16, os.cpu_count() or 1))
