@@ -299,7 +299,7 @@ void build_reference_bvh(const float *positions9, size_t n_tris, RefBvh &out)
 
 // ===================================================================================
 // Opt-in "SAH" acceleration structure: tight bounds, 16-bin surface-area
-// heuristic, leaves of <= 4 triangles (<= 2 for scenes of up to 262 144: sah_leaf_size_for), boxes inflated by a small epsilon so that pruning by
+// heuristic, leaves of <= 4 triangles (the product: <= 2, sah_leaf_size_for), boxes inflated by a small epsilon so that pruning by
 // distance stays conservative with respect to the Moller-Trumbore arithmetic.  It does NOT
 // reproduce the reference's set of tested triangles (that set is defined by the reference's
 // origin-containing boxes), so results can differ from the reference in ill-conditioned cases

@@ -1502,9 +1502,12 @@ static pt_status fill_params(pt_device *dev, RenderParams &P)
     // a tree in HBM, whose every step waits on memory, wants its idle lanes refilled early (C4: 80 % -> 67.5 ms; 50: 72.2,
     // 35: 77.3, 95: 81.4).  The 4-wide form's visits are fatter and fewer, which moves the big-scene optimum down
     // (C4: 57.4 / 57.9 / 53.0 / 55.0 / 56.0 / 58.0 / 65.8 ms at 30 / 40 / 50 / 60 / 70 / 80 / 90 %; C3 stays at 40).
+    // Round 4's tree (leaves of two, boxes 1e-5 of the magnitude wider instead of 1e-4 of the extent) moves it again: C4 35.0 /
+    // 31.6 / 31.9 / 32.2 / 32.8 / 33.7 ms at 20 / 25 / 30 / 35 / 40 / 50 %, C3 95.8 / 95.9 / 96.4 / 98.0 / 99.3 at 30 / 35 / 40 / 45 / 50:
+    // 30 for both 4-wide forms (the pair form keeps 80 / 40).
     {
         const size_t scene_bytes = dev->n_pairs * sizeof(NodePair) + dev->n_tris * sizeof(TriIsect);
-        P.spec_pct = dev->spec_pct >= 0 ? dev->spec_pct : (scene_bytes > ((size_t)64 << 20) ? (dev->sah_wide_on ? 50 : 80) : 40);
+        P.spec_pct = dev->spec_pct >= 0 ? dev->spec_pct : (dev->sah_wide_on ? 30 : scene_bytes > ((size_t)64 << 20) ? 80 : 40);
     }
     P.fold_bits = dev->fold_bits;
     P.deal_cap = 0; P.part_boxes = 0; P.deal_min = dev->deal_min; P.any_tex = dev->any_tex ? 1 : 0; P.lrpt = dev->lrpt;

@@ -93,7 +93,7 @@ struct MatRec {
     float er, eg, eb; int32_t emisTex;          // emissiveFactor_, emissiveTexture_
     float e50r, e50g, e50b; int32_t is_light;   // emissiveFactor_*50 (material.h:85)
 };
-// Opt-in SAH tree (pt_bvh.cpp): NodePair records in DFS pre-order, leaves of <= 4 triangles (2 for small scenes),
+// Opt-in SAH tree (pt_bvh.cpp): NodePair records in DFS pre-order, leaves of <= 4 triangles (the product builds with 2),
 // `order[slot]` = face index of the triangle stored at leaf-order slot `slot`.
 struct SahBvh {
     std::vector<NodePair> pairs;
@@ -102,11 +102,11 @@ struct SahBvh {
 };
 // max_leaf: ranges of at most this many triangles become leaves (the device forms take up to 15 per leaf).
 void build_sah_bvh(const float *positions9, size_t n_tris, SahBvh &out, uint32_t max_leaf = 4);
-// The leaf size the product builds with.  Trees that stay in the caches (they take the 128-byte float form) get leaves of
-// two: a triangle trip tests a pair, so every leaf is one trip and one round trip (the duck: 26.9 box + 4.2 triangle tests per
-// segment instead of 20.7 + 8.1, C3 100.4 -> 97.1 ms).  Big trees keep four: the 8.4 M-triangle terrain gains nothing from
-// two (45.4 against 45.5 ms) and would carry half again as many node records.  profiles/r04_c4_visit_slope.json
-inline uint32_t sah_leaf_size_for(size_t n_tris) { return n_tris <= ((size_t)1 << 18) ? 2u : 4u; }
+// The leaf size the product builds with: two.  A triangle trip tests a pair, so every leaf is one trip and one memory round
+// trip; the tree has twice the leaves (the 8.4 M-triangle terrain: 180 MB of 64-byte nodes instead of 90, 1.3 s more to build).
+// Leaves of 2 / 4 / 6 / 8: C4 33.3 / 34.5 / 36.4 / 40.6 ms, the duck through the SAH tree 96.7 / 100.5 / 105.3 / -- ms, the
+// Cornell box through it 56.0 / 68.0 ms (profiles/r04_c4_visit_slope.json).
+inline uint32_t sah_leaf_size_for(size_t /*n_tris*/) { return 2u; }
 
 // The SAH tree in 4-wide form for the device (pt_walk.h, wide SAH walk): a QuadNode holds up to four child boxes, made
 // from a pair by replacing its larger inner children with their own two children.  128 B = two NodePair-sized halves:
