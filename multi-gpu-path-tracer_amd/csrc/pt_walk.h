@@ -982,6 +982,8 @@ __device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W,
         float t5 = (b.x - o.z) * inv.z, t6 = (b.y - o.z) * inv.z;
         tnl = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
         float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+        // the per-ray margin of the 4-wide forms (sahq_node_eval), here on the interval itself: 2^-19 of its ends
+        tnl = fmaf(-fabsf(tnl), 1.9073486328125e-06f, tnl); tf = fmaf(fabsf(tf), 1.9073486328125e-06f, tf);
         hl = (tf >= fmaxf(tnl, 0.0f)) & (tnl <= W.tbest);
 #ifdef PT_STALE
         g_l = tf >= fmaxf(tnl, 0.0f);
@@ -992,6 +994,7 @@ __device__ __forceinline__ bool sah_node_step(const RenderParams &P, SahWalk &W,
         float t5 = (c.z - o.z) * inv.z, t6 = (c.w - o.z) * inv.z;
         tnr = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
         float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+        tnr = fmaf(-fabsf(tnr), 1.9073486328125e-06f, tnr); tf = fmaf(fabsf(tf), 1.9073486328125e-06f, tf);
         hr = (tf >= fmaxf(tnr, 0.0f)) & (tnr <= W.tbest);
 #ifdef PT_STALE
         g_r = tf >= fmaxf(tnr, 0.0f);
